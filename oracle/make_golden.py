@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE ITSELF (imported read-only
+from /root/reference) and HF transformers on seeded inputs.
+
+Runs only in the build container (the GPU box has no /root/reference):
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--big]
+
+Nothing of the reference is copied: the fixtures hold inputs and the outputs the
+reference computed (scores, orders, counters).  Checkpoints are NOT stored; they
+are regenerated from ``vllm_ltr_amd.opt_spec.seeded_checkpoint(spec, seed)``.
+
+Import shims: a stub ``cpuinfo`` module
+(vllm/usage/usage_lib.py:13), ``selector.is_cpu -> True`` so ``Attention`` picks
+the TorchSDPA backend (vllm/attention/selector.py:50-60), and a 1-rank gloo
+process group (vllm/distributed/parallel_state.py:52-77).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+sys.modules["cpuinfo"] = types.ModuleType("cpuinfo")
+import torch  # noqa: E402
+import vllm  # noqa: E402  (the reference, via PYTHONPATH)
+import vllm.attention.selector as _sel  # noqa: E402
+
+_sel.is_cpu = lambda: True
+from vllm.distributed import (ensure_model_parallel_initialized,  # noqa: E402
+                              init_distributed_environment)
+
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint  # noqa: E402
+
+assert vllm.__file__.startswith("/root/reference"), vllm.__file__
+
+
+def _init_dist():
+    init_distributed_environment(1, 0, "tcp://127.0.0.1:29577", 0, backend="gloo")
+    ensure_model_parallel_initialized(1, 1)
+
+
+# --------------------------------------------------------------------------------
+# predictor scores
+# --------------------------------------------------------------------------------
+def make_inputs(spec: OPTSpec, lens, seed):
+    rs = np.random.RandomState(seed)
+    ids = []
+    for L in lens:
+        row = rs.randint(4, spec.vocab_size, size=L)
+        row[0] = 2                                   # BOS first, like the OPT tokenizer
+        ids.append(row)
+    ids = np.concatenate(ids).astype(np.int64)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return ids, cu
+
+
+def ref_scores(spec: OPTSpec, ckpt, ids, cu):
+    """Drive vllm.model_executor.models.opt.OPTForSequenceClassification exactly as
+    ModelRunner.execute_model does for a prefill batch (model_runner.py:827-877)."""
+    from transformers import OPTConfig
+    from vllm.attention.backends.torch_sdpa import TorchSDPAMetadata
+    from vllm.model_executor.models.opt import OPTForSequenceClassification as REF
+    from vllm.model_executor.sampling_metadata import SamplingMetadata
+    cfg = OPTConfig(**spec.to_hf_config_kwargs())
+    torch.manual_seed(0)
+    ref = REF(cfg).eval().float()
+    ref.load_weights([(k, torch.from_numpy(v.astype(np.float32))) for k, v in ckpt.items()])
+    lens = np.diff(cu).tolist()
+    N, T = len(lens), int(cu[-1])
+    pos = torch.cat([torch.arange(L) for L in lens]).long()
+    sel = torch.as_tensor(cu[1:].astype(np.int64) - 1)
+    md = TorchSDPAMetadata(context_lens=None, max_context_len=None, block_tables=torch.tensor([]),
+                           num_prefills=N, num_prefill_tokens=T, num_decode_tokens=0,
+                           prefill_metadata=object(), decode_metadata=None,
+                           slot_mapping=torch.zeros(T, dtype=torch.long), kv_cache_dtype="auto",
+                           need_score=False, selected_token_indices=sel, is_prompt=True,
+                           prompt_lens=lens)
+    sm = SamplingMetadata(seq_groups=[], seq_data={}, prompt_lens=lens, selected_token_indices=sel,
+                          categorized_sample_indices=None, generators=None, perform_sampling=False)
+    with torch.no_grad():
+        hs, _ = ref(torch.from_numpy(ids), pos, [None] * cfg.num_hidden_layers, md)
+        logits = ref.compute_logits(hs, sm)           # opt.py:389-397 (argmax'd in class mode)
+        last_hidden = hs.index_select(0, sel)
+    return logits[:, 0].float().numpy(), last_hidden.float().numpy()
+
+
+def hf_logits(spec: OPTSpec, ckpt, ids, cu):
+    """HF OPTForSequenceClassification on the right-padded batch - the model that
+    prefill_predictor.py:25,50-53 wraps (the 'CPU reference predictor')."""
+    from transformers import OPTConfig, OPTForSequenceClassification as HF
+    cfg = OPTConfig(**spec.to_hf_config_kwargs())
+    cfg.pad_token_id = 1
+    hf = HF(cfg).eval().float()
+    sd = {k: torch.from_numpy(v.astype(np.float32)) for k, v in ckpt.items()}
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "lm_head" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    lens = np.diff(cu).tolist()
+    out = []
+    with torch.no_grad():
+        for i, L in enumerate(lens):                  # one by one: no padding effects at all
+            x = torch.from_numpy(ids[cu[i]:cu[i + 1]])[None]
+            out.append(hf(input_ids=x, attention_mask=torch.ones_like(x)).logits[0])
+    return torch.stack(out).float().numpy()
+
+
+def score_fixture(name, spec, lens, seed):
+    t0 = time.time()
+    ckpt = seeded_checkpoint(spec, seed)
+    ids, cu = make_inputs(spec, lens, seed + 1)
+    ref, last_hidden = ref_scores(spec, ckpt, ids, cu)
+    hfl = hf_logits(spec, ckpt, ids, cu)
+    if spec.num_labels == 1:
+        d = float(np.abs(hfl[:, 0] - ref).max())
+    else:
+        d = float(np.abs(hfl.argmax(-1).astype(np.float32) - ref).max())
+    print(f"{name}: N={len(lens)} T={int(cu[-1])} ref-vs-HF max|d|={d:.3e}  ({time.time()-t0:.1f}s)")
+    assert d < 5e-5, d
+    np.savez_compressed(os.path.join(GOLD, f"score_{name}.npz"),
+                        spec=np.array(list(spec.to_hf_config_kwargs().items()), dtype=object).astype(str),
+                        seed=np.int64(seed), ids=ids, cu_seqlens=cu, ref_score=ref.astype(np.float32),
+                        hf_logits=hfl.astype(np.float32),
+                        ref_last_hidden=last_hidden[:, :min(64, last_hidden.shape[1])].astype(np.float32))
+
+
+# --------------------------------------------------------------------------------
+# scheduler ranking
+# --------------------------------------------------------------------------------
+class _StubAux:
+    """Stands where llm_engine.py:228-242 puts the AUXLLM: sets a given score."""
+
+    def __init__(self, table):
+        self.table = table
+        self.calls = []
+
+    def obtain_aux_scores(self, sgs):
+        self.calls.append([sg.request_id for sg in sgs])
+        for sg in sgs:
+            assert sg.need_aux_model_score()
+            sg.set_aux_model_score(self.table[sg.request_id])
+
+
+def _mk_scheduler(schedule_type, max_tokens, max_seqs, blocks=4096, block_size=16):
+    from vllm.config import CacheConfig, SchedulerConfig
+    from vllm.core.scheduler import Scheduler
+    sc = SchedulerConfig(max_tokens, max_seqs, 2048, enable_chunked_prefill=True,
+                         schedule_type=schedule_type)
+    cc = CacheConfig(block_size, 1.0, 1, "auto")
+    cc.num_gpu_blocks = cc.num_cpu_blocks = blocks
+    return Scheduler(sc, cc, None)
+
+
+def _mk_sg(rid: str, plen: int, block_size=16):
+    from vllm import SamplingParams
+    from vllm.sequence import Sequence, SequenceGroup
+    seq = Sequence(int(rid) if rid.isdigit() else abs(hash(rid)) % 10**6, "p", list(range(plen)),
+                   block_size)
+    return SequenceGroup(rid, [seq], SamplingParams(max_tokens=10**6, ignore_eos=True), time.time())
+
+
+def order_fixture():
+    """Standalone calls of the reference's _get_{opt,tpt,rtpt,ropt}_ordered_requests
+    (scheduler.py:936-1016) on engineered score vectors, with requests spread over
+    waiting / running / swapped and pre-set (pri, idle, runs)."""
+    rs = np.random.RandomState(7)
+    cases = []
+
+    def scores_engineered(n):
+        s = rs.standard_normal(n).astype(np.float32)
+        s = s.astype(np.float16).astype(np.float32)           # fp16-valued like GPU scores
+        s[rs.randint(0, n, n // 4)] = s[rs.randint(0, n, n // 4)]   # many exact ties
+        s[rs.randint(0, n, max(1, n // 16))] = 0.0
+        s[rs.randint(0, n, max(1, n // 16))] = -0.0
+        return s
+
+    for ci, (n, starv, period) in enumerate([(5, -1, 0), (64, -1, 0), (64, 3, 2), (257, 5, 3),
+                                             (1000, 200, 10), (33, 0, 1), (128, 1, 1)]):
+        st = "opt-xxx" + (f"-starv{starv}-period{period}" if starv != -1 else "")
+        s = _mk_scheduler(st, 4096, 256)
+        sc = scores_engineered(n)
+        if ci == 0:
+            sc = np.array([0.5, 0.5, -0.0, 0.0, 1.0], np.float32)
+        ids = [str(i) for i in range(n)]
+        sgs = [_mk_sg(r, 4) for r in ids]
+        table = {r: float(x) for r, x in zip(ids, sc)}
+        s.aux_model = _StubAux(table)
+        # queue membership: first chunk waiting (unscored), then running, then swapped (scored)
+        n_w = n - 2 * (n // 3)
+        where = np.array([0] * n_w + [1] * (n // 3) + [2] * (n // 3))
+        pri0 = np.zeros(n, np.int32); idle0 = np.zeros(n, np.int32); runs0 = np.zeros(n, np.int32)
+        if starv != -1:
+            pri0 = -(rs.rand(n) < 0.3).astype(np.int32)
+            idle0 = rs.randint(0, max(2 * starv, 2), n).astype(np.int32)
+            runs0 = rs.randint(-1, period + 1, n).astype(np.int32)
+        for i, sg in enumerate(sgs):
+            s.add_seq_group(sg)                                  # sets idle=runs=pri=0, :372-374
+        for i, sg in enumerate(sgs):
+            sg.pri, sg.idle, sg.runs = int(pri0[i]), int(idle0[i]), int(runs0[i])
+            if where[i] != 0:
+                s.waiting.remove(sg)
+                sg.set_aux_model_score(table[sg.request_id])
+                (s.running if where[i] == 1 else s.swapped).append(sg)
+        order = [sg.request_id for sg in s._get_opt_ordered_requests()]
+        post = np.array([[sg.pri, sg.idle, sg.runs] for sg in sgs], np.int32)
+        extra = {}
+        if starv == -1:
+            extra["tpt"] = np.array([int(g.request_id) for g in s._get_tpt_ordered_requests()], np.int32)
+            extra["rtpt"] = np.array([int(g.request_id) for g in s._get_rtpt_ordered_requests()], np.int32)
+            extra["ropt"] = np.array([int(g.request_id) for g in s._get_ropt_ordered_requests()], np.int32)
+        cases.append(dict(score=sc, where=where.astype(np.int8), starv=starv, period=period,
+                          pri0=pri0, idle0=idle0, runs0=runs0,
+                          order=np.array([int(r) for r in order], np.int32), post=post,
+                          aux_calls=len(s.aux_model.calls), **extra))
+        print(f"order case {ci}: n={n} starv={starv} period={period} head={order[:6]}")
+    flat = {}
+    for ci, c in enumerate(cases):
+        for k, v in c.items():
+            flat[f"c{ci}_{k}"] = np.asarray(v)
+    flat["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "rank_order.npz"), **flat)
+
+
+def steps_fixture():
+    """Multi-step runs of the reference's full Scheduler.schedule() (= _general_schedule,
+    scheduler.py:1101-1373) with starvation control; per step we record the order
+    returned by _get_ordered_requests, which requests ran, and (pri, idle, runs) after
+    the aging loop (:1358-1365)."""
+    from vllm.sequence import Logprob
+    runs_out = {}
+    for fi, (n, starv, period, max_seqs, max_tokens, steps, plen) in enumerate(
+            [(10, 3, 2, 4, 64, 12, 4), (48, 4, 2, 6, 96, 24, 8), (200, 6, 3, 16, 256, 30, 5)]):
+        rs = np.random.RandomState(100 + fi)
+        st = f"opt-xxx-starv{starv}-period{period}"
+        s = _mk_scheduler(st, max_tokens, max_seqs)
+        sc = (np.arange(n) % 5).astype(np.float32) if fi == 0 else \
+            rs.standard_normal(n).astype(np.float16).astype(np.float32)
+        ids = [str(i) for i in range(n)]
+        table = {r: float(x) for r, x in zip(ids, sc)}
+        s.aux_model = _StubAux(table)
+        sgs = [_mk_sg(r, plen) for r in ids]
+        by_id = {g.request_id: g for g in sgs}
+        arrive_at = np.zeros(n, np.int32) if fi == 0 else np.sort(rs.randint(0, steps // 2, n)).astype(np.int32)
+        orders, rans, states, present = [], [], [], []
+        captured = {}
+        inner = s._get_ordered_requests
+
+        def spy():
+            o = inner()
+            captured["order"] = [g.request_id for g in o]
+            return o
+        s._get_ordered_requests = spy
+        for step in range(steps):
+            for i in np.nonzero(arrive_at == step)[0]:
+                s.add_seq_group(sgs[i])
+            metas, out = s.schedule()
+            ran = [x.seq_group.request_id for x in out.scheduled_seq_groups]
+            for x, meta in zip(out.scheduled_seq_groups, metas):
+                x.seq_group.update_num_computed_tokens(meta.token_chunk_size)
+                if not x.seq_group.is_prefill():
+                    for seq in x.seq_group.get_seqs():
+                        seq.append_token_id(1, {1: Logprob(0.0)})
+            alive = [g.request_id for g in list(s.waiting) + list(s.running) + list(s.swapped)]
+            o = np.full(n, -1, np.int32); o[:len(captured["order"])] = [int(r) for r in captured["order"]]
+            orders.append(o)
+            r = np.zeros(n, np.uint8); r[[int(x) for x in ran]] = 1
+            rans.append(r)
+            p = np.zeros(n, np.uint8); p[[int(x) for x in alive]] = 1
+            present.append(p)
+            stt = np.zeros((n, 3), np.int32)
+            for g in sgs:
+                if hasattr(g, "pri"):
+                    stt[int(g.request_id)] = (g.pri, g.idle, g.runs)
+            states.append(stt)
+        print(f"steps case {fi}: n={n} first orders {orders[0][:6]} ... step3 {orders[min(3, steps-1)][:8]}")
+        runs_out.update({f"f{fi}_score": sc, f"f{fi}_starv": np.int64(starv), f"f{fi}_period": np.int64(period),
+                         f"f{fi}_arrive_at": arrive_at, f"f{fi}_orders": np.stack(orders),
+                         f"f{fi}_ran": np.stack(rans), f"f{fi}_present": np.stack(present),
+                         f"f{fi}_states": np.stack(states)})
+    runs_out["n_cases"] = np.int64(3)
+    np.savez_compressed(os.path.join(GOLD, "rank_steps.npz"), **runs_out)
+
+
+def config_fixture():
+    """Round-trip the shipped predictor configs through the reference's
+    PrefillPredictorConfig.from_json (config_predictor.py:136-147) and record the
+    parsed fields; also the starv/period parse of scheduler.py:269-275."""
+    import json
+    from vllm.config_predictor import PrefillPredictorConfig
+    out = {}
+    cfgdir = "/root/reference/train/configs"
+    for fn in sorted(os.listdir(cfgdir)):
+        c = PrefillPredictorConfig.from_json(os.path.join(cfgdir, fn))
+        with open(os.path.join(cfgdir, fn)) as f:
+            raw = json.load(f)
+        out[fn] = dict(input=raw, parsed=dict(c.model.__dict__))
+    sts = {}
+    for st in ["opt-xxx-starv200-period10", "opt-starv3-period2", "opt-125m-sharegpt-starv256-period32",
+               "opt", "opt-class-starv0-period1"]:
+        s = _mk_scheduler(st, 64, 4)
+        sts[st] = dict(starv=s.starv, period=getattr(s, "period", 0), need_score=s.need_score)
+    with open(os.path.join(GOLD, "config_cases.json"), "w") as f:
+        json.dump(dict(predictor_configs=out, schedule_types=sts), f, indent=1, sort_keys=True)
+    print("config cases:", list(out), sts)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also the true-shape 125m / 350m cases")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    _init_dist()
+    torch.set_num_threads(os.cpu_count())
+    if args.only in ("", "config"):
+        config_fixture()
+    if args.only in ("", "order"):
+        order_fixture()
+    if args.only in ("", "steps"):
+        steps_fixture()
+    if args.only in ("", "score"):
+        edge = [1, 2, 4, 5, 63, 64, 65, 100, 3, 128, 17, 1, 31, 32, 33, 150]
+        score_fixture("tiny_pre_ln", OPTSpec.tiny_pre_ln(), edge, 11)
+        score_fixture("tiny_post_ln", OPTSpec.tiny_post_ln(), edge, 12)
+        score_fixture("tiny_pre_ln_class10", OPTSpec.tiny_pre_ln(10), edge, 13)
+        score_fixture("tiny_post_ln_class7", OPTSpec.tiny_post_ln(7), edge, 14)
+    if args.big:
+        big = [1, 2, 4, 5, 63, 64, 65, 200, 1024, 2048, 90, 33]
+        score_fixture("opt125m", OPTSpec.opt_125m(), big, 21)
+        score_fixture("opt350m", OPTSpec.opt_350m(), big[:9] + [300], 22)

@@ -1,0 +1,152 @@
+"""ORACLE (test infrastructure, not product code) - CPU restatement of the
+reference scheduler's per-step ranking: starvation promote/demote, the stable
+priority sort, and the post-schedule aging of the ``idle/runs`` counters.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.
+
+Reference (relative to /root/reference):
+* schedule-type grammar ``...starv<S>-period<P>``: vllm/core/scheduler.py:269-275
+* per-request state ``idle = runs = pri = 0`` on arrival: scheduler.py:372-374
+* promote / demote + ``sorted(..., key=(pri, -score))`` / ``key=-score``:
+  scheduler.py:984-998 (``_get_opt_ordered_requests``)
+* other orderings that share the kernel: ``tpt`` ``(-score, request_id)`` :948,
+  ``rtpt`` ``(score, request_id)`` :961, ``ropt`` ``score`` :1015
+* aging after the budget walk: scheduler.py:1337,1358-1365
+
+Pinning: ``oracle/make_golden.py`` drives the *reference's own*
+``Scheduler._get_opt_ordered_requests`` / ``Scheduler.schedule`` (imported from
+/root/reference in the build container) and stores orders + counters in
+``tests/golden/rank_*.npz``; ``tests/test_oracle_golden.py`` replays them here.
+
+Two forms are kept: the literal per-object Python (what the reference executes,
+used as the CPU baseline) and a NumPy form for 64k+ queues; tests check they
+agree.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+class Req:
+    """The fields of ``SequenceGroup`` the ranking touches
+    (sequence.py:426-433, scheduler.py:372-374)."""
+    __slots__ = ("request_id", "aux_model_score", "pri", "idle", "runs")
+
+    def __init__(self, request_id: str, score: Optional[float] = None):
+        self.request_id = request_id
+        self.aux_model_score = score
+        self.pri = 0
+        self.idle = 0
+        self.runs = 0
+
+    def need_aux_model_score(self) -> bool:          # sequence.py:461-462
+        return self.aux_model_score is None
+
+    def set_aux_model_score(self, s) -> None:        # sequence.py:464-465
+        self.aux_model_score = s
+
+
+def parse_starvation(schedule_type: str) -> Tuple[int, int]:
+    """scheduler.py:269-275 (same slicing arithmetic). Returns (starv, period);
+    starv == -1 means the feature is off."""
+    starv, period = -1, 0
+    if "starv" in schedule_type:
+        starv = int(schedule_type[schedule_type.find("starv") + len("starv"):
+                                  schedule_type.find("period") - 1])
+        period = int(schedule_type[schedule_type.find("period") + len("period"):])
+    return starv, period
+
+
+# ---- literal per-object form --------------------------------------------------
+def opt_order(reqs: Sequence[Req], starv: int, period: int) -> List[Req]:
+    """scheduler.py:984-998 over ``list(waiting)+list(running)+list(swapped)``."""
+    if starv != -1:
+        for r in reqs:
+            if r.idle >= starv:
+                r.pri = -1
+                r.idle = 0
+                r.runs = period
+            elif r.pri == -1 and r.runs <= 0:
+                r.pri = 0
+        return list(sorted(reqs, key=lambda req: (req.pri, -req.aux_model_score)))
+    return list(sorted(reqs, key=lambda req: -req.aux_model_score))
+
+
+def tpt_order(reqs: Sequence[Req]) -> List[Req]:      # scheduler.py:948
+    return list(sorted(reqs, key=lambda req: (-req.aux_model_score, req.request_id)))
+
+
+def rtpt_order(reqs: Sequence[Req]) -> List[Req]:     # scheduler.py:961
+    return list(sorted(reqs, key=lambda req: (req.aux_model_score, req.request_id)))
+
+
+def ropt_order(reqs: Sequence[Req]) -> List[Req]:     # scheduler.py:1015
+    return list(sorted(reqs, key=lambda req: req.aux_model_score))
+
+
+def age_update(all_pri: Sequence[Req], running_this_step: Sequence[Req]) -> None:
+    """scheduler.py:1358-1365 (membership is by object identity/equality there;
+    a set of ids gives the same answer in O(N))."""
+    ran = {id(r) for r in running_this_step}
+    for seq in all_pri:
+        if id(seq) in ran:
+            if seq.pri == -1:
+                seq.runs -= 1
+            seq.idle = 0
+        else:
+            seq.idle += 1
+
+
+# ---- NumPy array form ---------------------------------------------------------
+def promote_demote_np(pri, idle, runs, starv: int, period: int) -> None:
+    """In-place scheduler.py:986-993 on int32 arrays."""
+    if starv == -1:
+        return
+    promote = idle >= starv
+    demote = (~promote) & (pri == -1) & (runs <= 0)
+    pri[promote] = -1
+    idle[promote] = 0
+    runs[promote] = period
+    pri[demote] = 0
+
+
+def order_np(score, pri, tiebreak=None, use_pri: bool = True, ascending: bool = False):
+    """Permutation ``perm`` with ``perm[k]`` = input index of the k-th request.
+    Keys, most significant first: ``pri`` (if used), ``-score`` (or ``score``),
+    ``tiebreak`` (default: input index = Python's stable sort).  ``-0.0 == 0.0``
+    compare equal exactly as Python floats do."""
+    score = np.asarray(score, np.float32)
+    n = score.shape[0]
+    k = score.astype(np.float64)
+    k = k if ascending else -k
+    k = k + 0.0                                     # -0.0 + 0.0 -> +0.0
+    tb = np.arange(n, dtype=np.int64) if tiebreak is None else np.asarray(tiebreak, np.int64)
+    keys = (tb, k) + ((np.asarray(pri, np.int64),) if use_pri else ())
+    return np.lexsort(keys).astype(np.int32)
+
+
+def rank_step_np(score, pri, idle, runs, starv: int, period: int, tiebreak=None):
+    """promote/demote (in place) followed by the (pri, -score) order -
+    the array form of :func:`opt_order`."""
+    promote_demote_np(pri, idle, runs, starv, period)
+    return order_np(score, pri, tiebreak, use_pri=(starv != -1))
+
+
+def age_update_np(ran, pri, idle, runs) -> None:
+    """In-place scheduler.py:1358-1365 on arrays; ``ran`` is a bool/uint8 mask."""
+    ran = np.asarray(ran).astype(bool)
+    runs[ran & (pri == -1)] -= 1
+    idle[ran] = 0
+    idle[~ran] += 1
+
+
+def string_rank(request_ids: Sequence[str]) -> np.ndarray:
+    """Tiebreak key for the ``tpt`` orderings: rank of ``request_id`` under
+    Python *string* comparison (``"10" < "9"``), scheduler.py:948."""
+    order = sorted(range(len(request_ids)), key=lambda i: request_ids[i])
+    rank = np.empty(len(request_ids), np.int64)
+    rank[order] = np.arange(len(request_ids))
+    return rank

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests fail loudly (not skip) when selected with -m gpu on a box whose
+    HIP library or device is missing; without -m gpu they are deselected by the
+    driver's -m "not gpu"."""
+    return
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

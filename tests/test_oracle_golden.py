@@ -1,0 +1,163 @@
+"""The oracle (our CPU restatement) against vectors computed by the reference
+itself (oracle/make_golden.py, run in the build container against
+/root/reference).  CPU-only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rank_step as rs
+from oracle.opt_scorer import OracleOPTScorer
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+
+from conftest import GOLDEN
+
+
+def _spec_from(npz) -> OPTSpec:
+    kv = {k: v for k, v in npz["spec"]}
+    conv = {}
+    for k, v in kv.items():
+        conv[k] = (v == "True") if v in ("True", "False") else int(v)
+    return OPTSpec(**conv)
+
+
+SCORE_CASES = ["tiny_pre_ln", "tiny_post_ln", "tiny_pre_ln_class10", "tiny_post_ln_class7"]
+BIG_CASES = ["opt125m", "opt350m"]
+
+
+@pytest.mark.parametrize("name", SCORE_CASES + BIG_CASES)
+def test_scorer_matches_reference(name):
+    path = os.path.join(GOLDEN, f"score_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    z = np.load(path, allow_pickle=False)
+    spec = _spec_from(z)
+    if name in BIG_CASES and os.environ.get("LTR_BIG_ORACLE", "0") != "1":
+        # true-shape oracle runs take ~1 min of CPU each; covered on demand and by the GPU parity tests
+        pytest.skip("set LTR_BIG_ORACLE=1 for the true-shape oracle check")
+    ckpt = seeded_checkpoint(spec, int(z["seed"]))
+    orc = OracleOPTScorer(spec, ckpt)
+    got = orc.score(z["ids"], z["cu_seqlens"])
+    if spec.num_labels == 1:
+        np.testing.assert_allclose(got, z["ref_score"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(got, z["hf_logits"][:, 0], atol=2e-6, rtol=0)
+    else:
+        assert (got == z["ref_score"]).all()
+        assert (got == z["hf_logits"].argmax(-1)).all()
+    # batch-composition independence (SURVEY 7 'varlen batching'): packed == flat
+    packed = orc.score_packed(z["ids"], z["cu_seqlens"], max_tokens=256)
+    np.testing.assert_allclose(packed, got, atol=2e-6, rtol=0)
+
+
+def test_scorer_empty():
+    spec = OPTSpec.tiny_pre_ln()
+    orc = OracleOPTScorer(spec, seeded_checkpoint(spec, 1))
+    assert orc.score(np.zeros(0, np.int64), np.zeros(1, np.int32)).shape == (0,)
+
+
+def _load_order():
+    return np.load(os.path.join(GOLDEN, "rank_order.npz"), allow_pickle=False)
+
+
+def test_order_cases_literal_and_numpy():
+    z = _load_order()
+    for ci in range(int(z["n_cases"])):
+        g = lambda k: z[f"c{ci}_{k}"]
+        score, where = g("score"), g("where")
+        starv, period = int(g("starv")), int(g("period"))
+        n = len(score)
+        # concatenation order of the reference: waiting + running + swapped (scheduler.py:985,996)
+        concat = np.concatenate([np.nonzero(where == q)[0] for q in (0, 1, 2)])
+        reqs = [rs.Req(str(i), float(score[i])) for i in range(n)]
+        for i, r in enumerate(reqs):
+            r.pri, r.idle, r.runs = int(g("pri0")[i]), int(g("idle0")[i]), int(g("runs0")[i])
+        order = rs.opt_order([reqs[i] for i in concat], starv, period)
+        assert [int(r.request_id) for r in order] == g("order").tolist(), f"case {ci}"
+        post = np.array([[r.pri, r.idle, r.runs] for r in reqs], np.int32)
+        assert (post == g("post")).all()
+        # numpy form on the concatenated arrays
+        pri, idle, runs = (g("pri0")[concat].copy(), g("idle0")[concat].copy(), g("runs0")[concat].copy())
+        perm = rs.rank_step_np(score[concat], pri, idle, runs, starv, period)
+        assert concat[perm].tolist() == g("order").tolist(), f"case {ci} numpy"
+        assert (np.stack([pri, idle, runs], 1) == g("post")[concat]).all()
+        if starv == -1:
+            ids = [str(i) for i in concat]
+            tb = rs.string_rank(ids)
+            assert concat[rs.order_np(score[concat], None, tb, use_pri=False)].tolist() == g("tpt").tolist()
+            assert concat[rs.order_np(score[concat], None, tb, use_pri=False, ascending=True)].tolist() \
+                == g("rtpt").tolist()
+            assert concat[rs.order_np(score[concat], None, None, use_pri=False, ascending=True)].tolist() \
+                == g("ropt").tolist()
+            rq = [reqs[i] for i in concat]
+            assert [int(r.request_id) for r in rs.tpt_order(rq)] == g("tpt").tolist()
+            assert [int(r.request_id) for r in rs.rtpt_order(rq)] == g("rtpt").tolist()
+            assert [int(r.request_id) for r in rs.ropt_order(rq)] == g("ropt").tolist()
+
+
+def test_multi_step_schedule_replay():
+    """Replay the reference's multi-step runs: given which requests ran each step
+    (decided by the reference's budget walk, outside the ranking path), our
+    promote/demote + sort + aging must reproduce every order and every counter."""
+    z = np.load(os.path.join(GOLDEN, "rank_steps.npz"), allow_pickle=False)
+    for fi in range(int(z["n_cases"])):
+        g = lambda k: z[f"f{fi}_{k}"]
+        score, starv, period = g("score"), int(g("starv")), int(g("period"))
+        orders, ran, present, states, arrive = g("orders"), g("ran"), g("present"), g("states"), g("arrive_at")
+        n = len(score)
+        reqs = [rs.Req(str(i), float(score[i])) for i in range(n)]
+        pri = np.zeros(n, np.int32); idle = np.zeros(n, np.int32); runs = np.zeros(n, np.int32)
+        for step in range(orders.shape[0]):
+            want = orders[step][orders[step] >= 0]
+            members = sorted(want.tolist())            # who is queued this step
+            # the reference's concatenation order is not recorded; pri/score ties between
+            # queues are broken by it, so compare keys rather than ids where keys tie
+            got = rs.opt_order([reqs[i] for i in members], starv, period)
+            key = lambda r: (r.pri, -r.aux_model_score)
+            assert [key(r) for r in got] == [key(reqs[i]) for i in want], f"case {fi} step {step}"
+            sub = np.array(members, np.int64)
+            if len(sub):
+                p, i_, r_ = pri[sub].copy(), idle[sub].copy(), runs[sub].copy()
+                perm = rs.rank_step_np(score[sub], p, i_, r_, starv, period)
+                pri[sub], idle[sub], runs[sub] = p, i_, r_
+                assert [(int(pri[j]), -float(score[j])) for j in sub[perm]] == \
+                       [key(reqs[i]) for i in want]
+            alive = np.nonzero(present[step])[0]
+            rs.age_update([reqs[i] for i in alive], [reqs[i] for i in np.nonzero(ran[step])[0]])
+            if len(alive):
+                p, i_, r_ = pri[alive].copy(), idle[alive].copy(), runs[alive].copy()
+                rs.age_update_np(ran[step][alive], p, i_, r_)
+                pri[alive], idle[alive], runs[alive] = p, i_, r_
+            for i in alive:
+                assert (reqs[i].pri, reqs[i].idle, reqs[i].runs) == tuple(states[step][i]), \
+                    f"case {fi} step {step} req {i}"
+                assert (pri[i], idle[i], runs[i]) == tuple(states[step][i])
+
+
+def test_parse_starvation_matches_reference():
+    with open(os.path.join(GOLDEN, "config_cases.json")) as f:
+        cases = json.load(f)["schedule_types"]
+    for st, want in cases.items():
+        starv, period = rs.parse_starvation(st)
+        assert starv == want["starv"]
+        if starv != -1:
+            assert period == want["period"]
+
+
+def test_literal_vs_numpy_large_random():
+    r = np.random.RandomState(3)
+    for n, starv, period in [(4096, 50, 7), (8192, -1, 0), (3000, 0, 2)]:
+        score = r.standard_normal(n).astype(np.float16).astype(np.float32)
+        pri = -(r.rand(n) < 0.2).astype(np.int32)
+        idle = r.randint(0, 120, n).astype(np.int32)
+        runs = r.randint(-2, 8, n).astype(np.int32)
+        reqs = [rs.Req(str(i), float(score[i])) for i in range(n)]
+        for i, q in enumerate(reqs):
+            q.pri, q.idle, q.runs = int(pri[i]), int(idle[i]), int(runs[i])
+        lit = [int(q.request_id) for q in rs.opt_order(reqs, starv, period)]
+        perm = rs.rank_step_np(score, pri, idle, runs, starv, period)
+        assert lit == perm.tolist()
+        ranmask = (r.rand(n) < 0.1)
+        rs.age_update(reqs, [reqs[i] for i in np.nonzero(ranmask)[0]])
+        rs.age_update_np(ranmask, pri, idle, runs)
+        assert [(q.pri, q.idle, q.runs) for q in reqs] == list(zip(pri.tolist(), idle.tolist(), runs.tolist()))
