@@ -1,0 +1,199 @@
+/*
+ * ltr_hip.h - C ABI of libltr_hip.so, the MI355X (gfx950) implementation of
+ * vllm-ltr's per-step ranking hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * the reference checkout; see SURVEY.md section 8a/8b and INTEGRATION.md for the
+ * reference-side binding).
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers unless the name ends in _host.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*); nothing
+ *    synchronises except where stated.
+ *  - Return value: 0 on success, negative LTR_E_* code on failure; never throws.
+ *    ltr_last_error() returns a thread-local message for the last failure.
+ *  - N = number of requests, T = total prompt tokens, L_i = cu_seqlens[i+1]-cu_seqlens[i].
+ */
+#ifndef LTR_HIP_H
+#define LTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTR_ABI_VERSION 1
+
+enum {
+  LTR_OK = 0,
+  LTR_E_INVAL = -22,   /* bad argument / unsupported shape                  */
+  LTR_E_NOMEM = -12,   /* workspace too small                               */
+  LTR_E_HIP = -5,      /* a HIP runtime call failed (see ltr_last_error)    */
+  LTR_E_NODEV = -19    /* no gfx950 device                                  */
+};
+
+/* weight element type of matrices and embedding tables */
+enum { LTR_W_F32 = 0, LTR_W_F16 = 1 };
+
+/* Shape of the predictor: HF OPTConfig fields of an OPTForSequenceClassification
+ * (vllm/model_executor/models/opt.py:362-376; train/trainer.py:213-216). */
+typedef struct ltr_model_desc {
+  int32_t vocab_size;
+  int32_t hidden_size;          /* H  */
+  int32_t ffn_dim;              /* F  */
+  int32_t num_layers;           /* Nl */
+  int32_t num_heads;            /* head size H/num_heads must be 64 */
+  int32_t word_embed_proj_dim;  /* De; != H adds project_in/out (opt.py:205-219) */
+  int32_t pos_rows;             /* rows of the position table = max_position_embeddings + 2 (opt.py:43-53) */
+  int32_t num_labels;           /* rows of score.weight (opt.py:374) */
+  int32_t pre_ln;               /* do_layer_norm_before: 1 = 125m style, 0 = 350m style (opt.py:145-176) */
+  int32_t weight_dtype;         /* LTR_W_F32: exact f32 MFMA path; LTR_W_F16: fp16 weights x (hi+lo) fp16
+                                   split activations, f32 accumulate */
+} ltr_model_desc;
+
+/* Order of the device pointers handed to ltr_create (HF tensor names in comments).
+ * Matrices / tables are row-major [out, in] in `weight_dtype`; biases, LayerNorm
+ * affine terms are always f32.  q,k,v are stacked in that order (opt.py:411-417). */
+enum {
+  LTR_WT_EMBED_TOKENS = 0,   /* model.decoder.embed_tokens.weight      [V, De]        */
+  LTR_WT_EMBED_POS,          /* model.decoder.embed_positions.weight   [pos_rows, H]  */
+  LTR_WT_PROJECT_IN,         /* model.decoder.project_in.weight        [H, De] | NULL */
+  LTR_WT_PROJECT_OUT,        /* model.decoder.project_out.weight       [De, H] | NULL */
+  LTR_WT_FINAL_LN_W,         /* model.decoder.final_layer_norm.weight  [H] f32 | NULL */
+  LTR_WT_FINAL_LN_B,         /* model.decoder.final_layer_norm.bias    [H] f32 | NULL */
+  LTR_WT_SCORE,              /* score.weight                           [num_labels, De] */
+  LTR_WT_GLOBAL_COUNT
+};
+enum {
+  LTR_WL_QKV_W = 0,  /* self_attn.{q,k,v}_proj.weight stacked  [3H, H] */
+  LTR_WL_QKV_B,      /* ... bias stacked                        [3H] f32 */
+  LTR_WL_OUT_W,      /* self_attn.out_proj.weight               [H, H]  */
+  LTR_WL_OUT_B,      /*                                         [H] f32 */
+  LTR_WL_LN1_W,      /* self_attn_layer_norm.weight             [H] f32 */
+  LTR_WL_LN1_B,
+  LTR_WL_FC1_W,      /* fc1.weight                              [F, H]  */
+  LTR_WL_FC1_B,      /*                                         [F] f32 */
+  LTR_WL_FC2_W,      /* fc2.weight                              [H, F]  */
+  LTR_WL_FC2_B,      /*                                         [H] f32 */
+  LTR_WL_LN2_W,      /* final_layer_norm.weight (per layer)     [H] f32 */
+  LTR_WL_LN2_B,
+  LTR_WL_COUNT
+};
+/* total pointers = LTR_WT_GLOBAL_COUNT + num_layers * LTR_WL_COUNT */
+
+typedef struct ltr_model* ltr_handle;
+
+int ltr_abi_version(void);
+const char* ltr_last_error(void);
+
+/* Replaces loading the AUX engine's model: AUXLLM(...) -> Worker.load_model ->
+ * OPTForSequenceClassification.load_weights (vllm/engine/llm_engine.py:224-240,
+ * vllm/model_executor/models/opt.py:411-444).  The library keeps the POINTERS (the
+ * caller owns the weight memory and must keep it alive until ltr_destroy). */
+int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights,
+               ltr_handle* out);
+int ltr_destroy(ltr_handle h);
+
+/* Workspace sizing.  kind: */
+enum { LTR_WS_SCORE = 0, LTR_WS_RANK = 1 };
+size_t ltr_workspace_bytes(ltr_handle h /* may be NULL for LTR_WS_RANK */, int32_t kind,
+                           int64_t N, int64_t T);
+/* Tokens processed per internal pass of ltr_score (request-aligned chunks keep the
+ * activations of a pass resident in the 256 MiB Infinity Cache).  0 restores the default. */
+int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens);
+
+/* The predictor forward for a flat varlen batch: replaces one drain of the AUX
+ * engine, i.e. AUXLLMEngine.obtain_aux_scores' step loop (vllm/engine/
+ * aux_llm_engine.py:398-405) = ModelRunner.execute_model (vllm/worker/
+ * model_runner.py:827-877) = OPTForSequenceClassification.forward +
+ * compute_logits + sample's logits[:,0] (opt.py:378-409).
+ *   token_ids   int64 [T]   flat prompts (model_runner.py:711-716 input_tokens)
+ *   cu_seqlens  int32 [N+1] prefix sums of L_i (model_runner.py:383-395 seq_start_loc);
+ *               positions 0..L_i-1 and the last-token selection cu[i+1]-1
+ *               (model_runner.py:592-593) are derived from it on the device
+ *   cu_seqlens_host  the same array in host memory (the caller built it there);
+ *               lets the library cut request-aligned chunks without a device sync.
+ *               NULL: the library copies it back (one synchronising hipMemcpy).
+ *   scores_out  f32 [N]: rank mode logits[:,0] (opt.py:408); class mode (num_labels>1)
+ *               float(argmax_j logits[:, j]) (opt.py:394-395)
+ *   logits_out  f32 [N, num_labels] or NULL (raw head output, for tests/telemetry)  */
+int ltr_score(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
+              const int32_t* cu_seqlens_host, int32_t N, int32_t T, int32_t max_len,
+              float* scores_out, float* logits_out, void* workspace, size_t ws_bytes,
+              void* stream);
+
+/* Same forward stopped after `n_layers` decoder layers (n_layers < 0: all), writing the
+ * f32 hidden states [T, H] (before final LN / project_out).  Test / debugging hook for
+ * per-layer parity against the oracle (opt.py:145-176).  T must fit one chunk. */
+int ltr_forward_hidden(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
+                       const int32_t* cu_seqlens_host, int32_t N, int32_t T, int32_t max_len,
+                       int32_t n_layers, float* hidden_out, void* workspace, size_t ws_bytes,
+                       void* stream);
+
+/* The two HBM-bound ends of the forward, individually addressable for roofline work.
+ *
+ * Embedding gather: OPTDecoder.forward's first three lines (opt.py:241-245),
+ * VocabParallelEmbedding.forward (layers/vocab_parallel_embedding.py:95-106) and
+ * OPTLearnedPositionalEmbedding (+2 offset, opt.py:43-53).
+ *   De == H: hidden_out[t,:] = E_tok[ids[t],:] + E_pos[pos(t)+2,:]           (f32 [T,H])
+ *   De != H: hidden_out[t,:] = E_pos[pos(t)+2,:]; tok_out = E_tok rows, to be multiplied
+ *            by project_in (f32 [T,De] in the F32 mode; fp16 hi|lo planes [2][T,De] in F16) */
+int ltr_embed_gather(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
+                     int32_t N, int32_t T, float* hidden_out, void* tok_out, void* stream);
+
+/* Pool + final LayerNorm (or project_out) + score head: _prune_hidden_states
+ * (layers/logits_processor.py:74-79), the final LN / project_out of opt.py:259-262
+ * applied to the N selected rows only (both are per-token maps), _get_logits
+ * (logits_processor.py:61-71) with score.weight (opt.py:374), class-mode argmax
+ * (opt.py:394-395).  hidden: f32 [T, H] decoder output. */
+int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, int32_t N,
+                  float* scores_out, float* logits_out, void* stream);
+
+/* One ranking step over the queued requests: the body of
+ * Scheduler._get_opt_ordered_requests after scoring (vllm/core/scheduler.py:984-998).
+ *   1. if starv != -1, per request (in place, scheduler.py:986-993):
+ *        idle >= starv            -> pri = -1, idle = 0, runs = period
+ *        elif pri == -1, runs <= 0 -> pri = 0
+ *   2. perm_out = stable ascending sort of the N requests by
+ *        (pri [only if starv != -1 or LTR_RANK_USE_PRI], -score, tiebreak)
+ *      with -0.0 == +0.0; tiebreak NULL = input index, which is exactly Python's stable
+ *      sorted() over list(waiting)+list(running)+list(swapped) (scheduler.py:996,998).
+ *      For the tpt/rtpt orders (scheduler.py:948,961) pass the rank of request_id under
+ *      string comparison as tiebreak; LTR_RANK_ASCENDING sorts by +score (ropt/rtpt, :1015).
+ *      tiebreak values must be < 2^31.  NaN scores sort after every number.
+ *   scores f32 [N]; pri/idle/runs int32 [N]; perm_out int32 [N], perm_out[k] = input index
+ *   of the k-th request to schedule. */
+enum { LTR_RANK_USE_PRI = 1, LTR_RANK_ASCENDING = 2 };
+int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs,
+                  const uint32_t* tiebreak, int32_t N, int32_t starv, int32_t period,
+                  uint32_t flags, int32_t* perm_out, void* workspace, size_t ws_bytes,
+                  void* stream);
+
+/* Post-schedule aging, the loop at the end of Scheduler._general_schedule
+ * (vllm/core/scheduler.py:1358-1365): ran[i] != 0 -> (pri == -1: runs -= 1), idle = 0;
+ * else idle += 1.  ran u8 [N]. */
+int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int32_t N,
+                   void* stream);
+
+/* Next row in scope: the selection the budget walk of
+ * Scheduler._general_schedule makes over the ranked order (scheduler.py:1137-1211, with
+ * _get_num_new_tokens :1867-1888 and SchedulingBudget.can_schedule :51-55), as one scan:
+ * request k of perm is selected iff for every j <= k: new_tokens_j > 0,
+ * sum_{i<j} new_tokens_i < token_budget (a chunked prefill is granted
+ * min(need, remaining)), sum_{i<=j} new_seqs_i <= max_num_seqs, and a group with
+ * new_seqs > 1 (never chunked) fits whole; the walk stops at the first k that fails.
+ *   new_tokens / new_seqs  int32 [N] indexed by request (not by rank)
+ *   n_selected_out int32 [1]; ran_out u8 [N] or NULL (1 = selected; feeds ltr_age_update);
+ *   granted_out int32 [N] or NULL (tokens granted this step, 0 if not selected). */
+int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs,
+                      int32_t N, int64_t token_budget, int64_t max_num_seqs,
+                      int32_t* n_selected_out, uint8_t* ran_out, int32_t* granted_out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTR_HIP_H */

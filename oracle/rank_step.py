@@ -150,3 +150,26 @@ def string_rank(request_ids: Sequence[str]) -> np.ndarray:
     rank = np.empty(len(request_ids), np.int64)
     rank[order] = np.arange(len(request_ids))
     return rank
+
+
+# ---- budget walk (next row in scope) --------------------------------
+def budget_walk(order_need_tokens, order_need_seqs, token_budget: int, max_num_seqs: int):
+    """Literal restatement of the selection loop of Scheduler._general_schedule
+    (scheduler.py:1137-1211) for one ranked order: per request, in order,
+    ``num_new_tokens = min(need, budget.remaining_token_budget())`` when the group has a
+    single sequence (_get_num_new_tokens, :1867-1888, enable_chunking=True at :1128),
+    ``break`` if ``num_new_tokens == 0 or not budget.can_schedule(...)`` (:51-55).
+    Returns (n_selected, granted tokens per position)."""
+    used_tokens = 0
+    used_seqs = 0
+    granted = []
+    for need, nseq in zip(order_need_tokens, order_need_seqs):
+        n = int(need)
+        if nseq == 1:
+            n = min(n, token_budget - used_tokens)
+        if n == 0 or not (used_tokens + n <= token_budget and used_seqs + nseq <= max_num_seqs):
+            break
+        used_tokens += n
+        used_seqs += int(nseq)
+        granted.append(n)
+    return len(granted), granted

@@ -1,0 +1,165 @@
+"""-m gpu: the rank kernels (through the C ABI) against the oracle and the vectors the
+reference produced.  Integer / index work -> bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rank_step as rs
+from util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _run_rank(dev, score, pri, idle, runs, starv, period, tiebreak=None, ascending=False, use_pri=None):
+    from vllm_ltr_amd.rank import RankWorkspace, rank_step
+    ws = RankWorkspace(dev)
+    t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    s = t(score, torch.float32)
+    p, i, r = t(pri, torch.int32), t(idle, torch.int32), t(runs, torch.int32)
+    tb = t(tiebreak, torch.int32)
+    perm = rank_step(s, p, i, r, starv, period, ws, tiebreak=tb, ascending=ascending, use_pri=use_pri)
+    torch.cuda.synchronize()
+    back = lambda x: None if x is None else x.cpu().numpy()
+    return perm.cpu().numpy(), back(p), back(i), back(r)
+
+
+def test_golden_order_cases(dev):
+    z = np.load(os.path.join(GOLDEN, "rank_order.npz"))
+    for ci in range(int(z["n_cases"])):
+        g = lambda k: z[f"c{ci}_{k}"]
+        score, where = g("score"), g("where")
+        starv, period = int(g("starv")), int(g("period"))
+        concat = np.concatenate([np.nonzero(where == q)[0] for q in (0, 1, 2)])
+        perm, p, i, r = _run_rank(dev, score[concat], g("pri0")[concat], g("idle0")[concat], g("runs0")[concat],
+                                  starv, period)
+        assert concat[perm].tolist() == g("order").tolist(), f"case {ci}"
+        assert (np.stack([p, i, r], 1) == g("post")[concat]).all(), f"case {ci} counters"
+        if starv == -1:
+            ids = [str(k) for k in concat]
+            tb = rs.string_rank(ids)
+            perm, *_ = _run_rank(dev, score[concat], None, None, None, -1, 0, tiebreak=tb)
+            assert concat[perm].tolist() == g("tpt").tolist()
+            perm, *_ = _run_rank(dev, score[concat], None, None, None, -1, 0, tiebreak=tb, ascending=True)
+            assert concat[perm].tolist() == g("rtpt").tolist()
+            perm, *_ = _run_rank(dev, score[concat], None, None, None, -1, 0, ascending=True)
+            assert concat[perm].tolist() == g("ropt").tolist()
+
+
+@pytest.mark.parametrize("n,starv,period", [(1, -1, 0), (2, 0, 1), (63, 3, 2), (64, -1, 0), (65, 5, 1),
+                                            (1000, 200, 10), (1025, 2, 2), (8192, 200, 10), (8192, -1, 0),
+                                            (20000, 7, 3), (65536, 200, 10), (100003, -1, 0)])
+def test_rank_step_vs_oracle(dev, n, starv, period):
+    r = np.random.RandomState(n + 7 * starv)
+    score = r.standard_normal(n).astype(np.float32).astype(np.float16).astype(np.float32)   # many ties
+    score[r.randint(0, n, max(1, n // 20))] = 0.0
+    score[r.randint(0, n, max(1, n // 20))] = -0.0
+    pri = -(r.rand(n) < 0.2).astype(np.int32)
+    idle = r.randint(0, max(2, 2 * max(starv, 1)), n).astype(np.int32)
+    runs = r.randint(-2, period + 2, n).astype(np.int32)
+    perm, p, i, rr = _run_rank(dev, score, pri, idle, runs, starv, period)
+    ep, ei, er = pri.copy(), idle.copy(), runs.copy()
+    want = rs.rank_step_np(score, ep, ei, er, starv, period)
+    assert (perm == want).all()
+    assert (p == ep).all() and (i == ei).all() and (rr == er).all()
+    assert sorted(perm.tolist()) == list(range(n))      # a permutation (size-independent property)
+
+
+def test_rank_empty_and_inf(dev):
+    perm, *_ = _run_rank(dev, np.zeros(0, np.float32), np.zeros(0, np.int32), np.zeros(0, np.int32),
+                         np.zeros(0, np.int32), 3, 2)
+    assert perm.shape == (0,)
+    score = np.array([np.inf, -np.inf, 1.0, -1.0, 0.0, -0.0, np.inf], np.float32)
+    perm, *_ = _run_rank(dev, score, None, None, None, -1, 0)
+    assert perm.tolist() == rs.order_np(score, None, use_pri=False).tolist() == [0, 6, 2, 4, 5, 3, 1]
+
+
+def test_literal_python_equivalence(dev):
+    """Against the literal per-object Python (what the reference executes)."""
+    r = np.random.RandomState(5)
+    n, starv, period = 4096, 50, 7
+    score = r.standard_normal(n).astype(np.float16).astype(np.float32)
+    reqs = [rs.Req(str(k), float(score[k])) for k in range(n)]
+    for q in reqs:
+        q.pri, q.idle, q.runs = -int(r.rand() < 0.3), int(r.randint(0, 100)), int(r.randint(-1, 9))
+    pri = np.array([q.pri for q in reqs], np.int32)
+    idle = np.array([q.idle for q in reqs], np.int32)
+    runs = np.array([q.runs for q in reqs], np.int32)
+    lit = [int(q.request_id) for q in rs.opt_order(reqs, starv, period)]
+    perm, p, i, rr = _run_rank(dev, score, pri, idle, runs, starv, period)
+    assert perm.tolist() == lit
+    assert [(q.pri, q.idle, q.runs) for q in reqs] == list(zip(p.tolist(), i.tolist(), rr.tolist()))
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000, 8192, 65536])
+def test_age_update(dev, n):
+    from vllm_ltr_amd.rank import age_update
+    r = np.random.RandomState(n)
+    pri = -(r.rand(n) < 0.3).astype(np.int32)
+    idle = r.randint(0, 100, n).astype(np.int32)
+    runs = r.randint(-3, 10, n).astype(np.int32)
+    ran = (r.rand(n) < 0.25).astype(np.uint8)
+    d = [torch.from_numpy(a.copy()).to(dev) for a in (pri, idle, runs)]
+    age_update(torch.from_numpy(ran).to(dev), *d)
+    rs.age_update_np(ran, pri, idle, runs)
+    assert (d[0].cpu().numpy() == pri).all() and (d[1].cpu().numpy() == idle).all() and (d[2].cpu().numpy() == runs).all()
+
+
+def test_multi_step_replay_of_reference_runs(dev):
+    """The reference's own multi-step schedule() runs (tests/golden/rank_steps.npz):
+    device-resident counters, kernels only."""
+    from vllm_ltr_amd.rank import RankWorkspace, age_update, rank_step
+    z = np.load(os.path.join(GOLDEN, "rank_steps.npz"))
+    ws = RankWorkspace(dev)
+    for fi in range(int(z["n_cases"])):
+        g = lambda k: z[f"f{fi}_{k}"]
+        score, starv, period = g("score"), int(g("starv")), int(g("period"))
+        orders, ran, present, states = g("orders"), g("ran"), g("present"), g("states")
+        n = len(score)
+        pri = torch.zeros(n, dtype=torch.int32, device=dev)
+        idle = torch.zeros_like(pri); runs = torch.zeros_like(pri)
+        sc = torch.from_numpy(score).to(dev)
+        for step in range(orders.shape[0]):
+            want = orders[step][orders[step] >= 0]
+            members = torch.from_numpy(np.sort(want).astype(np.int64)).to(dev)
+            if len(want):
+                p, i_, r_ = pri[members].contiguous(), idle[members].contiguous(), runs[members].contiguous()
+                perm = rank_step(sc[members].contiguous(), p, i_, r_, starv, period, ws)
+                pri[members], idle[members], runs[members] = p, i_, r_
+                got = members[perm.long()].cpu().numpy()
+                key = lambda j: (int(pri[j]), -float(score[j]))
+                assert [key(j) for j in got] == [key(j) for j in want], f"case {fi} step {step}"
+            alive = torch.from_numpy(np.nonzero(present[step])[0]).to(dev)
+            if alive.numel():
+                p, i_, r_ = pri[alive].contiguous(), idle[alive].contiguous(), runs[alive].contiguous()
+                age_update(torch.from_numpy(ran[step]).to(dev)[alive].contiguous(), p, i_, r_)
+                pri[alive], idle[alive], runs[alive] = p, i_, r_
+                st = torch.stack([pri, idle, runs], 1).cpu().numpy()
+                a = alive.cpu().numpy()
+                assert (st[a] == states[step][a]).all(), f"case {fi} step {step}"
+
+
+@pytest.mark.parametrize("n,budget,max_seqs", [(1, 10, 1), (100, 64, 4), (1000, 2048, 256), (8192, 4096, 256),
+                                               (8192, 10**6, 10**6), (5000, 300, 10**6)])
+def test_budget_prefix(dev, n, budget, max_seqs):
+    from vllm_ltr_amd.rank import budget_prefix
+    r = np.random.RandomState(n + budget)
+    perm = r.permutation(n).astype(np.int32)
+    need = r.randint(1, 64, n).astype(np.int32)
+    if n > 50:
+        need[r.randint(0, n, 2)] = 0
+    seqs = np.ones(n, np.int32)
+    nsel, ran, granted = budget_prefix(torch.from_numpy(perm).to(dev), torch.from_numpy(need).to(dev),
+                                       torch.from_numpy(seqs).to(dev), budget, max_seqs)
+    want_n, want_g = rs.budget_walk(need[perm], seqs[perm], budget, max_seqs)
+    assert int(nsel.item()) == want_n
+    ran = ran.cpu().numpy(); granted = granted.cpu().numpy()
+    assert (ran[perm[:want_n]] == 1).all() and ran.sum() == want_n
+    assert granted[perm[:want_n]].tolist() == want_g and granted.sum() == sum(want_g)

@@ -1,0 +1,225 @@
+"""-m gpu: the HIP predictor forward (through the C ABI) against the CPU oracle and the
+vectors the reference itself produced (tests/golden/score_*.npz).
+
+Tolerance: BASELINE.json north_star - scores within 1e-4 of the fp32 CPU predictor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.opt_scorer import OracleOPTScorer
+from util import GOLDEN, bench_lengths, spec_from_npz, synthetic_batch
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # north_star tolerance on scores
+TOL_HIDDEN = 2e-4   # on O(1..10) hidden-state entries
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return "cuda:0"
+
+
+def _scorer(spec, ckpt, dev, mode, **kw):
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    return HipOPTScorer(spec, ckpt, device=dev, weight_dtype=mode, **kw)
+
+
+TINY = ["tiny_pre_ln", "tiny_post_ln", "tiny_pre_ln_class10", "tiny_post_ln_class7"]
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("name", TINY)
+def test_golden_tiny(dev, name, mode):
+    z = np.load(os.path.join(GOLDEN, f"score_{name}.npz"))
+    spec = spec_from_npz(z)
+    ckpt = seeded_checkpoint(spec, int(z["seed"]))
+    sc = _scorer(spec, ckpt, dev, mode)
+    got, logits = sc.score(z["ids"], z["cu_seqlens"], return_logits=True)
+    if spec.num_labels == 1:
+        err = np.abs(got - z["ref_score"]).max()
+        print(f"{name}/{mode}: max|score - reference| = {err:.3e}")
+        assert err <= TOL
+        np.testing.assert_allclose(logits[:, 0], z["hf_logits"][:, 0], atol=TOL, rtol=0)
+    else:
+        np.testing.assert_allclose(logits, z["hf_logits"], atol=TOL, rtol=0)
+        # class mode: float(argmax) (opt.py:394-395); a flipped argmax is only legitimate
+        # when the top two logits are closer than the tolerance
+        top2 = np.sort(z["hf_logits"], -1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 2 * TOL
+        assert (got[safe] == z["ref_score"][safe]).all()
+
+
+@pytest.mark.parametrize("name,mode", [("opt125m", "f16"), ("opt125m", "f32"), ("opt350m", "f16")])
+def test_golden_true_shape(dev, name, mode):
+    path = os.path.join(GOLDEN, f"score_{name}.npz")
+    assert os.path.exists(path), "true-shape fixture missing: run oracle/make_golden.py --big"
+    z = np.load(path)
+    spec = spec_from_npz(z)
+    ckpt = seeded_checkpoint(spec, int(z["seed"]))
+    sc = _scorer(spec, ckpt, dev, mode)
+    got = sc.score(z["ids"], z["cu_seqlens"])
+    err = np.abs(got - z["ref_score"]).max()
+    print(f"{name}/{mode}: N={len(got)} T={int(z['cu_seqlens'][-1])} max|score - reference| = {err:.3e}")
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("mk", [OPTSpec.tiny_pre_ln, OPTSpec.tiny_post_ln])
+def test_per_layer_hidden_vs_oracle(dev, mk, mode):
+    spec = mk()
+    ckpt = seeded_checkpoint(spec, 5)
+    ids, cu = synthetic_batch(spec, [7, 1, 64, 65, 2, 130, 33], 9)
+    orc = OracleOPTScorer(spec, ckpt)
+    sc = _scorer(spec, ckpt, dev, mode)
+    for nl in range(spec.num_hidden_layers + 1):
+        want = orc.hidden(ids, cu, n_layers=nl).numpy()
+        got = sc.hidden(ids, cu, n_layers=nl)
+        err = np.abs(got - want).max()
+        assert err <= TOL_HIDDEN, f"layers={nl}: {err}"
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_embed_gather_kernel_alone(dev, mode):
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 3)
+    ids, cu = synthetic_batch(spec, [5, 1, 100, 64, 3], 4)
+    sc = _scorer(spec, ckpt, dev, mode)
+    T, N = int(cu[-1]), len(cu) - 1
+    out = torch.empty(T, spec.hidden_size, device=dev)
+    sc.embed_gather_device(torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev), N, T, out)
+    orc = OracleOPTScorer(spec, ckpt)
+    want = orc.hidden(ids, cu, n_layers=0).numpy()
+    assert np.array_equal(out.cpu().numpy(), want)      # gather + one f32 add: bit-exact
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("mk", [OPTSpec.tiny_pre_ln, OPTSpec.tiny_post_ln, lambda: OPTSpec.tiny_post_ln(5)])
+def test_pool_head_kernel_alone(dev, mk, mode):
+    spec = mk()
+    ckpt = seeded_checkpoint(spec, 3)
+    lens = [5, 1, 100, 64, 3]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T, N = int(cu[-1]), len(lens)
+    h = torch.randn(T, spec.hidden_size, generator=torch.Generator().manual_seed(1)) * 2.0
+    sc = _scorer(spec, ckpt, dev, mode)
+    scores = torch.empty(N, device=dev)
+    logits = torch.empty(N, spec.num_labels, device=dev)
+    sc.pool_head_device(h.to(dev), torch.from_numpy(cu).to(dev), N, scores, logits)
+    orc = OracleOPTScorer(spec, ckpt)
+    want = orc.pool_head(h, torch.as_tensor(cu[1:].astype(np.int64) - 1)).numpy()
+    np.testing.assert_allclose(logits.cpu().numpy(), want, atol=2e-5, rtol=0)
+    if spec.num_labels == 1:
+        np.testing.assert_allclose(scores.cpu().numpy(), want[:, 0], atol=2e-5, rtol=0)
+    else:
+        assert (scores.cpu().numpy() == want.argmax(-1)).all()
+
+
+def test_chunking_is_invisible(dev):
+    """Scores do not depend on how the batch is cut into passes."""
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 8)
+    lens = bench_lengths(300, seed=1, mu=24.0).clip(1, 150)
+    ids, cu = synthetic_batch(spec, lens.tolist(), 2)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    whole = sc.score(ids, cu)
+    sc.set_chunk_tokens(200)          # many request-aligned chunks
+    parts = sc.score(ids, cu)
+    assert np.array_equal(whole, parts)
+    orc = OracleOPTScorer(spec, ckpt)
+    assert np.abs(whole - orc.score(ids, cu)).max() <= TOL
+
+
+def test_edge_inputs(dev):
+    from vllm_ltr_amd._lib import LtrError
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 8)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    assert sc.score(np.zeros(0, np.int64), np.zeros(1, np.int32)).shape == (0,)     # empty batch
+    orc = OracleOPTScorer(spec, ckpt)
+    ids, cu = synthetic_batch(spec, [1], 1)                                         # single 1-token request
+    assert abs(sc.score(ids, cu)[0] - orc.score(ids, cu)[0]) <= TOL
+    L = spec.max_position_embeddings                                                # maximum length
+    ids, cu = synthetic_batch(spec, [L, 1, L], 2)
+    assert np.abs(sc.score(ids, cu) - orc.score(ids, cu)).max() <= TOL
+    with pytest.raises(LtrError):                                                   # over-long prompt
+        i2, c2 = synthetic_batch(spec, [L + 1], 3)
+        sc.score(i2, c2)
+    with pytest.raises(LtrError):                                                   # empty request
+        sc.score(np.array([2, 5], np.int64), np.array([0, 0, 2], np.int32))
+
+
+def test_bench_profile_properties_125m(dev):
+    """At the BASELINE profile (true 125m shape) with sizes the oracle cannot finish
+    quickly: size-independent properties - permutation invariance and determinism -
+    plus an oracle spot check on a sub-sample."""
+    spec = OPTSpec.opt_125m()
+    ckpt = seeded_checkpoint(spec, 0)
+    n = 512
+    lens = bench_lengths(n, seed=0)
+    ids, cu = synthetic_batch(spec, lens.tolist(), 0)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    s1 = sc.score(ids, cu)
+    s2 = sc.score(ids, cu)
+    assert np.array_equal(s1, s2)                                   # deterministic
+    perm = np.random.RandomState(1).permutation(n)                  # request order does not matter
+    ids_p = np.concatenate([ids[cu[i]:cu[i + 1]] for i in perm])
+    cu_p = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.int32)
+    s3 = sc.score(ids_p, cu_p)
+    assert np.abs(s3 - s1[perm]).max() <= 2e-5
+    sub = np.arange(0, n, 37)[:12]                                  # oracle on a sub-sample
+    orc = OracleOPTScorer(spec, ckpt)
+    ids_s = np.concatenate([ids[cu[i]:cu[i + 1]] for i in sub])
+    cu_s = np.concatenate([[0], np.cumsum(lens[sub])]).astype(np.int32)
+    err = np.abs(orc.score(ids_s, cu_s) - s1[sub]).max()
+    print(f"125m bench-profile spot check: max|d| = {err:.3e}")
+    assert err <= TOL
+
+
+def test_plugin_surface(dev):
+    """obtain_aux_scores / ordered_requests / age on SequenceGroup-like objects
+    against the literal reference expressions."""
+    from oracle import rank_step as rs
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 4)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    ranker = MI355XRanker(sc, "opt-xxx-starv3-period2", max_length=100)
+    r = np.random.RandomState(0)
+    groups = [FakeSeqGroup(str(i), [2] + r.randint(4, spec.vocab_size, r.randint(1, 140)).tolist()) for i in range(40)]
+
+    class Sched:
+        pass
+    s = Sched()
+    from collections import deque
+    s.waiting, s.running, s.swapped = deque(groups), deque(), deque()
+    ranker.install(s)
+    order = s._get_ordered_requests()
+    assert all(g.aux_model_score is not None for g in groups)
+    orc = OracleOPTScorer(spec, ckpt)
+    for g in groups[:8]:                                   # truncation to max_length (aux_llm_engine.py:365-369)
+        ids = np.array(g.prompt_token_ids[:100], np.int64)
+        want = orc.score(ids, np.array([0, len(ids)], np.int32))[0]
+        assert abs(g.aux_model_score - want) <= TOL
+    # same order as the literal reference expression on the same scores
+    mirror = [rs.Req(g.request_id, g.aux_model_score) for g in groups]
+    lit = rs.opt_order(mirror, 3, 2)
+    assert [g.request_id for g in order] == [m.request_id for m in lit]
+    # a few steps of aging + re-ranking
+    for step in range(6):
+        ran = order[:5]
+        ranker.age(groups, ran)
+        ran_ids = {g.request_id for g in ran}
+        rs.age_update(mirror, [m for m in mirror if m.request_id in ran_ids])
+        assert [(g.pri, g.idle, g.runs) for g in groups] == [(m.pri, m.idle, m.runs) for m in mirror]
+        order = s._get_ordered_requests()
+        lit = rs.opt_order(mirror, 3, 2)
+        assert [g.request_id for g in order] == [m.request_id for m in lit]
+        assert [(g.pri, g.idle, g.runs) for g in groups] == [(m.pri, m.idle, m.runs) for m in mirror]
+    assert ranker.stats["aux_calls"] == 1                   # scored once, cached (sequence.py:461-465)

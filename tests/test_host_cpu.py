@@ -1,0 +1,140 @@
+"""CPU-only: host logic, config/schedule-string mirrors, checkpoint IO, and that the
+C-ABI library loads and exports every symbol include/ltr_hip.h declares."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from vllm_ltr_amd import _lib
+from vllm_ltr_amd.config_predictor import PrefillPredictorConfig
+from vllm_ltr_amd.opt_spec import (OPTSpec, load_hf_checkpoint, save_hf_checkpoint, seeded_checkpoint,
+                                   tensor_shapes)
+from vllm_ltr_amd.schedule_type import parse_schedule_type
+
+
+def _built():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _built()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ltr_hip.h")).read()
+    declared = set(re.findall(r"\b(ltr_[a-z_]+)\s*\(", header))
+    declared -= {"ltr_model_desc"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ltr_abi_version() == 1
+
+
+def test_library_argument_errors_without_gpu():
+    """Argument validation paths never touch the device."""
+    import ctypes as C
+    _built()
+    lib = _lib.load()
+    h = C.c_void_p()
+    desc = _lib.ModelDesc(512, 100, 512, 2, 2, 128, 162, 1, 1, _lib.LTR_W_F16)     # head size != 64
+    ptrs = (C.c_void_p * 31)()
+    assert lib.ltr_create(C.byref(desc), ptrs, 31, C.byref(h)) == -22
+    assert b"head size" in lib.ltr_last_error()
+    desc = _lib.ModelDesc(512, 128, 512, 2, 2, 128, 162, 1, 1, _lib.LTR_W_F16)
+    assert lib.ltr_create(C.byref(desc), ptrs, 30, C.byref(h)) == -22               # wrong pointer count
+    assert lib.ltr_create(C.byref(desc), ptrs, 31, C.byref(h)) == -22               # NULL weights
+    assert lib.ltr_workspace_bytes(None, _lib.LTR_WS_RANK, 8192, 0) >= 8192 * 12
+    with pytest.raises(_lib.LtrError):
+        _lib.check(-22, "x")
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vllm_ltr_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_scorer_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.tiny_pre_ln()
+    with pytest.raises(_lib.LtrError):
+        HipOPTScorer(spec, seeded_checkpoint(spec, 0))
+
+
+def test_predictor_config_matches_reference_parse():
+    cases = json.load(open(os.path.join(GOLDEN, "config_cases.json")))["predictor_configs"]
+    assert cases
+    for fn, c in cases.items():
+        cfg = PrefillPredictorConfig.from_dict(c["input"])
+        assert dict(cfg.model.__dict__) == c["parsed"], fn
+
+
+def test_predictor_config_roundtrip(tmp_path):
+    cfg = PrefillPredictorConfig.from_dict({"model": {"pred_model": "facebook/opt-125m", "num_labels": 1,
+                                                      "mtype": "rank", "activation": None,
+                                                      "path": "/x/finetuned", "max_length": 2048,
+                                                      "max_batch_size": 1000}})
+    p = tmp_path / "usage_config.json"
+    PrefillPredictorConfig.to_json(cfg, str(p))
+    again = PrefillPredictorConfig.from_json(str(p))
+    assert again == cfg
+    with pytest.raises(TypeError):
+        PrefillPredictorConfig.from_dict({"model": {"pred_model": "x", "num_labels": 1, "mtype": "rank",
+                                                    "activation": None, "bogus": 1}})
+
+
+def test_schedule_type_matches_reference_parse():
+    cases = json.load(open(os.path.join(GOLDEN, "config_cases.json")))["schedule_types"]
+    for st, want in cases.items():
+        got = parse_schedule_type(st)
+        assert got.starv == want["starv"] and got.need_score == want["need_score"]
+        if got.starv != -1:
+            assert got.period == want["period"]
+        assert got.policy == "opt"
+    assert parse_schedule_type("tpt-abc").policy == "tpt"
+    assert not parse_schedule_type("fifo").need_score
+    with pytest.raises(AssertionError):
+        parse_schedule_type("bogus")
+    with pytest.raises(ValueError):            # the reference's slicing fails the same way
+        parse_schedule_type("opt-starv5")
+
+
+def test_seeded_checkpoint_is_deterministic_and_fp16():
+    spec = OPTSpec.tiny_post_ln(3)
+    a, b = seeded_checkpoint(spec, 7), seeded_checkpoint(spec, 7)
+    assert list(a) == [n for n, _ in tensor_shapes(spec)]
+    for k in a:
+        assert a[k].dtype == np.float16 and np.array_equal(a[k], b[k])
+    assert not np.array_equal(a["score.weight"], seeded_checkpoint(spec, 8)["score.weight"])
+    n125 = sum(int(np.prod(s)) for _, s in tensor_shapes(OPTSpec.opt_125m()))
+    assert n125 == 125_239_296 + 768            # params (+ score head)
+    n350 = sum(int(np.prod(s)) for _, s in tensor_shapes(OPTSpec.opt_350m()))
+    assert n350 == 331_196_416 + 512
+
+
+def test_hf_checkpoint_roundtrip(tmp_path):
+    spec = OPTSpec.tiny_post_ln(3)
+    ck = seeded_checkpoint(spec, 1)
+    save_hf_checkpoint(str(tmp_path), spec, ck)
+    spec2, ck2 = load_hf_checkpoint(str(tmp_path))
+    assert spec2 == spec
+    for k in ck:
+        assert np.array_equal(ck[k], ck2[k])
+
+
+def test_pack_layout():
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    ids, cu = HipOPTScorer.pack([[2, 5, 6], [2], [2, 9]])
+    assert ids.tolist() == [2, 5, 6, 2, 2, 9] and cu.tolist() == [0, 3, 4, 6]
+    assert ids.dtype == np.int64 and cu.dtype == np.int32
+    ids, cu = HipOPTScorer.pack([])
+    assert ids.shape == (0,) and cu.tolist() == [0]

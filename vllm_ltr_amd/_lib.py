@@ -1,0 +1,74 @@
+"""ctypes binding of libltr_hip.so (include/ltr_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a call
+returns an error code, this raises.  PyTorch is used by the callers only for
+device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
+
+LTR_W_F32, LTR_W_F16 = 0, 1
+LTR_WS_SCORE, LTR_WS_RANK = 0, 1
+LTR_RANK_USE_PRI, LTR_RANK_ASCENDING = 1, 2
+LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
+
+# every symbol include/ltr_hip.h declares (tests check the library exports them all)
+SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
+           "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
+           "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix")
+
+
+class LtrError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "vocab_size", "hidden_size", "ffn_dim", "num_layers", "num_heads", "word_embed_proj_dim",
+        "pos_rows", "num_labels", "pre_ln", "weight_dtype")]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libltr_hip.so (built in-tree by ``python -m vllm_ltr_amd.csrc.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LtrError(f"{LIB_PATH} not found - build it with `python -m vllm_ltr_amd.csrc.build` "
+                       "(there is no CPU fallback for the ranking path)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_size_t
+    lib.ltr_abi_version.restype = C.c_int
+    lib.ltr_last_error.restype = C.c_char_p
+    lib.ltr_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp), i32, C.POINTER(vp)]
+    lib.ltr_destroy.argtypes = [vp]
+    lib.ltr_workspace_bytes.argtypes = [vp, i32, i64, i64]
+    lib.ltr_workspace_bytes.restype = sz
+    lib.ltr_set_chunk_tokens.argtypes = [vp, i32]
+    lib.ltr_score.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    lib.ltr_forward_hidden.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
+    lib.ltr_embed_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.ltr_pool_head.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    lib.ltr_rank_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, sz, vp]
+    lib.ltr_age_update.argtypes = [vp, vp, vp, vp, i32, vp]
+    lib.ltr_budget_prefix.argtypes = [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ltr_last_error().decode(errors="replace")
+        raise LtrError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,56 @@
+"""Build libltr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m vllm_ltr_amd.csrc.build [--force]
+
+Objects and the shared library are written next to the sources (in-tree, git-ignored)
+so the library travels with the repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["ltr_api.hip", "ltr_rank.hip", "ltr_rows.hip", "ltr_gemm.hip", "ltr_attn.hip", "ltr_pool.hip"]
+HEADERS = ["ltr_internal.h", os.path.join("..", "..", "include", "ltr_hip.h")]
+LIB = os.path.join(HERE, "libltr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc"]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(HERE, src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
+    if force or _stale(obj, deps):
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False) -> str:
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

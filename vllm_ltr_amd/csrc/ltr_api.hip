@@ -1,0 +1,366 @@
+// C-ABI of libltr_hip.so (include/ltr_hip.h) and the host-side orchestration of one
+// predictor forward: request-aligned chunks of the flat varlen batch are pushed through
+// embed -> Nl x (LN, QKV GEMM, varlen causal attention, out_proj, LN, fc1+ReLU, fc2) ->
+// pool + head, all enqueued on the caller's stream without host synchronisation.
+//
+// Reference control flow being replaced: AUXLLMEngine.obtain_aux_scores' step loop
+// (vllm/engine/aux_llm_engine.py:398-405) -> Worker.execute_model -> ModelRunner.execute_model
+// (vllm/worker/model_runner.py:827-877) -> OPTForSequenceClassification (opt.py:378-409).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ltr_internal.h"
+
+namespace ltr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace ltr
+
+using namespace ltr;
+
+struct ltr_model {
+  ltr_model_desc d;
+  std::vector<const void*> w;
+  int chunk_tokens;
+  const void* gw(int i) const { return w[i]; }
+  const void* lw(int layer, int i) const { return w[LTR_WT_GLOBAL_COUNT + layer * LTR_WL_COUNT + i]; }
+};
+
+namespace {
+
+constexpr int DEFAULT_CHUNK_TOKENS = 16384;
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// workspace carve-up for one chunk of at most Tc tokens / Nc requests
+struct Workspace {
+  float* h;        // f32 [Tc, H]      residual stream
+  AOp a;           // operand [Tc, H]  LN out / attention out / (De!=H: token rows)
+  float* qkv;      // f32 [Tc, 3H]
+  AOp f;           // operand [Tc, F]  ReLU(fc1)
+  int32_t* blk;    // int32 [Nc + 1]
+  size_t bytes;
+};
+
+Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base) {
+  const size_t H = d.hidden_size, F = d.ffn_dim;
+  const size_t esz = 4;   // operand bytes per element: f32, or fp16 hi + fp16 lo
+  char* p = (char*)base;
+  size_t off = 0;
+  Workspace ws{};
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n); return base ? (void*)(p + o) : (void*)nullptr; };
+  ws.h = (float*)take(Tc * H * 4);
+  char* a = (char*)take(Tc * H * esz);
+  ws.qkv = (float*)take(Tc * 3 * H * 4);
+  char* f = (char*)take(Tc * F * esz);
+  ws.blk = (int32_t*)take((Nc + 1) * 4);
+  if (d.weight_dtype == LTR_W_F16) {
+    ws.a = AOp{a, a ? a + Tc * H * 2 : nullptr};
+    ws.f = AOp{f, f ? f + Tc * F * 2 : nullptr};
+  } else {
+    ws.a = AOp{a, nullptr};
+    ws.f = AOp{f, nullptr};
+  }
+  ws.bytes = off;
+  return ws;
+}
+
+// one request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch
+int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev, int N_total, int r0, int r1, int t0,
+                  int t1, int n_layers, const Workspace& ws, hipStream_t s) {
+  const ltr_model_desc& d = m->d;
+  const int wd = d.weight_dtype;
+  const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim;
+  const int Tc = t1 - t0, nreq = r1 - r0;
+  int rc;
+  // --- embedding (opt.py:241-245)
+  rc = launch_embed_gather(wd, ids, cu_dev, N_total, Tc, t0, m->gw(LTR_WT_EMBED_TOKENS), De, d.vocab_size,
+                           m->gw(LTR_WT_EMBED_POS), H, d.pos_rows, ws.h, ws.a, s);
+  if (rc) return rc;
+  if (De != H) {   // h = project_in(tok) + pos : GEMM with the position rows as residual (in place)
+    GemmArgs g{};
+    g.a = ws.a; g.w = m->gw(LTR_WT_PROJECT_IN); g.bias = nullptr; g.resid = ws.h; g.out_f32 = ws.h;
+    g.M = Tc; g.N = H; g.K = De;
+    if ((rc = launch_gemm(wd, g, s))) return rc;
+  }
+  if (!d.pre_ln) {   // post-LN blocks consume h itself as the first GEMM operand
+    if ((rc = launch_to_operand(wd, ws.h, (int64_t)Tc * H, ws.a, s))) return rc;
+  }
+  const int nl = n_layers < 0 ? d.num_layers : (n_layers < d.num_layers ? n_layers : d.num_layers);
+  for (int L = 0; L < nl; ++L) {
+    // --- attention half (opt.py:152-163)
+    if (d.pre_ln) {
+      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), Tc,
+                            H, nullptr, ws.a, s);
+      if (rc) return rc;
+    }
+    {
+      GemmArgs g{};
+      g.a = ws.a; g.w = m->lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
+      g.out_f32 = ws.qkv; g.M = Tc; g.N = 3 * H; g.K = H;
+      if ((rc = launch_gemm(wd, g, s))) return rc;
+    }
+    rc = launch_attention(wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads, ws.blk, ws.a, s);
+    if (rc) return rc;
+    {
+      GemmArgs g{};
+      g.a = ws.a; g.w = m->lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
+      g.resid = ws.h; g.out_f32 = ws.h; g.M = Tc; g.N = H; g.K = H;
+      if ((rc = launch_gemm(wd, g, s))) return rc;
+    }
+    if (!d.pre_ln) {   // 350m: LN after the residual add; h and its operand copy
+      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), Tc,
+                            H, ws.h, ws.a, s);
+      if (rc) return rc;
+    }
+    // --- feed-forward half (opt.py:165-175)
+    if (d.pre_ln) {
+      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), Tc,
+                            H, nullptr, ws.a, s);
+      if (rc) return rc;
+    }
+    {
+      GemmArgs g{};
+      g.a = ws.a; g.w = m->lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
+      g.out_split = ws.f; g.relu = 1; g.M = Tc; g.N = F; g.K = H;
+      if ((rc = launch_gemm(wd, g, s))) return rc;
+    }
+    {
+      GemmArgs g{};
+      g.a = ws.f; g.w = m->lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
+      g.resid = ws.h; g.out_f32 = ws.h; g.M = Tc; g.N = H; g.K = F;
+      if ((rc = launch_gemm(wd, g, s))) return rc;
+    }
+    if (!d.pre_ln) {
+      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), Tc,
+                            H, ws.h, ws.a, s);
+      if (rc) return rc;
+    }
+  }
+  return LTR_OK;
+}
+
+int check_desc(const ltr_model_desc& d) {
+  if (d.hidden_size <= 0 || d.num_heads <= 0 || d.hidden_size != d.num_heads * 64) {
+    set_error("ltr_create: head size must be 64 (H=%d, heads=%d)", d.hidden_size, d.num_heads);
+    return LTR_E_INVAL;
+  }
+  if (d.hidden_size % 32 || d.ffn_dim % 32 || d.word_embed_proj_dim % 32 || d.hidden_size > 2048 ||
+      d.word_embed_proj_dim > 2048) {
+    set_error("ltr_create: H, F, De must be multiples of 32; H, De <= 2048");
+    return LTR_E_INVAL;
+  }
+  if (d.weight_dtype != LTR_W_F32 && d.weight_dtype != LTR_W_F16) {
+    set_error("ltr_create: unknown weight dtype %d", d.weight_dtype);
+    return LTR_E_INVAL;
+  }
+  if (d.num_labels < 1 || d.num_layers < 0 || d.vocab_size < 1 || d.pos_rows < 3) {
+    set_error("ltr_create: bad num_labels/num_layers/vocab/pos_rows");
+    return LTR_E_INVAL;
+  }
+  return LTR_OK;
+}
+
+// tokens per chunk: never below the longest legal request (pos_rows - 2 positions)
+int64_t chunk_cap(const ltr_model* m) {
+  const int64_t maxpos = m->d.pos_rows - 2;
+  return m->chunk_tokens > maxpos ? m->chunk_tokens : maxpos;
+}
+
+// host copy of cu_seqlens (caller's mirror, or a synchronising copy back)
+int host_cu(const int32_t* cu_dev, const int32_t* cu_host, int N, std::vector<int32_t>& tmp, const int32_t** out,
+            hipStream_t s) {
+  if (cu_host) { *out = cu_host; return LTR_OK; }
+  tmp.resize(N + 1);
+  LTR_HIP_CHECK(hipMemcpyAsync(tmp.data(), cu_dev, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  LTR_HIP_CHECK(hipStreamSynchronize(s));
+  *out = tmp.data();
+  return LTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ltr_abi_version(void) { return LTR_ABI_VERSION; }
+const char* ltr_last_error(void) { return ltr::g_err; }
+
+int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights, ltr_handle* out) {
+  if (!desc || !weights || !out) { set_error("ltr_create: NULL argument"); return LTR_E_INVAL; }
+  int rc = check_desc(*desc);
+  if (rc) return rc;
+  const int want = LTR_WT_GLOBAL_COUNT + desc->num_layers * LTR_WL_COUNT;
+  if (n_weights != want) { set_error("ltr_create: %d weight pointers, expected %d", n_weights, want); return LTR_E_INVAL; }
+  const bool proj = desc->word_embed_proj_dim != desc->hidden_size;
+  for (int i = 0; i < want; ++i) {
+    bool optional = (i == LTR_WT_PROJECT_IN || i == LTR_WT_PROJECT_OUT) ? !proj
+                    : (i == LTR_WT_FINAL_LN_W || i == LTR_WT_FINAL_LN_B) ? true : false;
+    if (!weights[i] && !optional) { set_error("ltr_create: weight pointer %d is NULL", i); return LTR_E_INVAL; }
+  }
+  if ((weights[LTR_WT_FINAL_LN_W] == nullptr) != (weights[LTR_WT_FINAL_LN_B] == nullptr)) {
+    set_error("ltr_create: final LN weight/bias must both be set or both NULL");
+    return LTR_E_INVAL;
+  }
+  ltr_model* m = new (std::nothrow) ltr_model();
+  if (!m) { set_error("ltr_create: out of host memory"); return LTR_E_NOMEM; }
+  m->d = *desc;
+  m->w.assign(weights, weights + want);
+  m->chunk_tokens = DEFAULT_CHUNK_TOKENS;
+  *out = m;
+  return LTR_OK;
+}
+
+int ltr_destroy(ltr_handle h) {
+  delete h;
+  return LTR_OK;
+}
+
+int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens) {
+  if (!h || chunk_tokens < 0) { set_error("ltr_set_chunk_tokens: bad argument"); return LTR_E_INVAL; }
+  h->chunk_tokens = chunk_tokens == 0 ? DEFAULT_CHUNK_TOKENS : chunk_tokens;
+  return LTR_OK;
+}
+
+size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
+  if (kind == LTR_WS_RANK) return rank_workspace_bytes(N);
+  if (kind == LTR_WS_SCORE && h) {
+    int64_t Tc = T < chunk_cap(h) ? T : chunk_cap(h);
+    int64_t Nc = N < Tc ? N : Tc;
+    return carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr).bytes;
+  }
+  return 0;
+}
+
+static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, const int32_t* cu_host_in,
+                       int32_t N, int32_t T, int32_t n_layers, float* hidden_out, float* scores_out,
+                       float* logits_out, void* workspace, size_t ws_bytes, hipStream_t s) {
+  if (!h) { set_error("ltr_score: NULL handle"); return LTR_E_INVAL; }
+  if (N < 0 || T < 0) { set_error("ltr_score: negative size"); return LTR_E_INVAL; }
+  if (N == 0) return LTR_OK;
+  if (!token_ids || !cu_seqlens || !workspace) { set_error("ltr_score: NULL pointer"); return LTR_E_INVAL; }
+  std::vector<int32_t> tmp;
+  const int32_t* cu = nullptr;
+  int rc = host_cu(cu_seqlens, cu_host_in, N, tmp, &cu, s);
+  if (rc) return rc;
+  if (cu[0] != 0 || cu[N] != T) { set_error("ltr_score: cu_seqlens[0]=%d cu_seqlens[N]=%d, T=%d", cu[0], cu[N], T); return LTR_E_INVAL; }
+  const ltr_model_desc& d = h->d;
+  const int max_pos = d.pos_rows - 2;
+  // chunk budget from the workspace actually provided
+  int64_t Tc_cap = chunk_cap(h);
+  while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr).bytes > ws_bytes) Tc_cap /= 2;
+  int r0 = 0;
+  while (r0 < N) {
+    int r1 = r0;
+    while (r1 < N && (int64_t)cu[r1 + 1] - cu[r0] <= Tc_cap) {
+      const int L = cu[r1 + 1] - cu[r1];
+      if (L <= 0) { set_error("ltr_score: request %d has length %d (empty prompts are not schedulable)", r1, L); return LTR_E_INVAL; }
+      if (L > max_pos) { set_error("ltr_score: request %d has %d tokens > max positions %d (truncate first, aux_llm_engine.py:365-369)", r1, L, max_pos); return LTR_E_INVAL; }
+      ++r1;
+    }
+    if (r1 == r0) {
+      const int L = cu[r0 + 1] - cu[r0];
+      if (L <= 0) { set_error("ltr_score: request %d has length %d", r0, L); return LTR_E_INVAL; }
+      set_error("ltr_score: workspace of %zu bytes cannot hold request %d (%d tokens)", ws_bytes, r0, L);
+      return LTR_E_NOMEM;
+    }
+    const int t0 = cu[r0], t1 = cu[r1];
+    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace);
+    if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
+    if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
+    rc = forward_chunk(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, s);
+    if (rc) return rc;
+    if (hidden_out) {
+      LTR_HIP_CHECK(hipMemcpyAsync(hidden_out, ws.h, (size_t)(t1 - t0) * d.hidden_size * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+      rc = launch_pool_head(d.weight_dtype, ws.h, cu_seqlens + r0, t0, r1 - r0, d.hidden_size, d.word_embed_proj_dim,
+                            d.num_labels, (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
+                            d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
+                            h->gw(LTR_WT_SCORE), scores_out + r0, logits_out ? logits_out + (size_t)r0 * d.num_labels : nullptr, s);
+      if (rc) return rc;
+    }
+    r0 = r1;
+  }
+  return LTR_OK;
+}
+
+int ltr_score(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, const int32_t* cu_seqlens_host,
+              int32_t N, int32_t T, int32_t max_len, float* scores_out, float* logits_out, void* workspace,
+              size_t ws_bytes, void* stream) {
+  (void)max_len;
+  if (N > 0 && !scores_out) { set_error("ltr_score: scores_out is NULL"); return LTR_E_INVAL; }
+  return run_forward(h, token_ids, cu_seqlens, cu_seqlens_host, N, T, -1, nullptr, scores_out, logits_out, workspace,
+                     ws_bytes, (hipStream_t)stream);
+}
+
+int ltr_forward_hidden(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
+                       const int32_t* cu_seqlens_host, int32_t N, int32_t T, int32_t max_len, int32_t n_layers,
+                       float* hidden_out, void* workspace, size_t ws_bytes, void* stream) {
+  (void)max_len;
+  if (N > 0 && !hidden_out) { set_error("ltr_forward_hidden: hidden_out is NULL"); return LTR_E_INVAL; }
+  return run_forward(h, token_ids, cu_seqlens, cu_seqlens_host, N, T, n_layers, hidden_out, nullptr, nullptr, workspace,
+                     ws_bytes, (hipStream_t)stream);
+}
+
+int ltr_embed_gather(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, int32_t N, int32_t T,
+                     float* hidden_out, void* tok_out, void* stream) {
+  if (!h || !token_ids || !cu_seqlens || !hidden_out) { set_error("ltr_embed_gather: NULL argument"); return LTR_E_INVAL; }
+  const ltr_model_desc& d = h->d;
+  const bool proj = d.word_embed_proj_dim != d.hidden_size;
+  if (proj && !tok_out) { set_error("ltr_embed_gather: tok_out required when De != H"); return LTR_E_INVAL; }
+  AOp tok{tok_out, nullptr};
+  if (proj && d.weight_dtype == LTR_W_F16) tok.lo = (char*)tok_out + (size_t)T * d.word_embed_proj_dim * 2;
+  return launch_embed_gather(d.weight_dtype, token_ids, cu_seqlens, N, T, 0, h->gw(LTR_WT_EMBED_TOKENS),
+                             d.word_embed_proj_dim, d.vocab_size, h->gw(LTR_WT_EMBED_POS), d.hidden_size, d.pos_rows,
+                             hidden_out, tok, (hipStream_t)stream);
+}
+
+int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, int32_t N, float* scores_out,
+                  float* logits_out, void* stream) {
+  if (!h || !hidden || !cu_seqlens || !scores_out) { set_error("ltr_pool_head: NULL argument"); return LTR_E_INVAL; }
+  const ltr_model_desc& d = h->d;
+  return launch_pool_head(d.weight_dtype, hidden, cu_seqlens, 0, N, d.hidden_size, d.word_embed_proj_dim, d.num_labels,
+                          (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
+                          d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
+                          h->gw(LTR_WT_SCORE), scores_out, logits_out, (hipStream_t)stream);
+}
+
+int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak, int32_t N,
+                  int32_t starv, int32_t period, uint32_t flags, int32_t* perm_out, void* workspace, size_t ws_bytes,
+                  void* stream) {
+  if (N < 0) { set_error("ltr_rank_step: negative N"); return LTR_E_INVAL; }
+  if (N == 0) return LTR_OK;
+  if (!scores || !perm_out || !workspace) { set_error("ltr_rank_step: NULL argument"); return LTR_E_INVAL; }
+  return launch_rank_step(scores, pri, idle, runs, tiebreak, N, starv, period, flags, perm_out, workspace, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int32_t N, void* stream) {
+  if (N < 0) { set_error("ltr_age_update: negative N"); return LTR_E_INVAL; }
+  if (N == 0) return LTR_OK;
+  if (!ran || !pri || !idle || !runs) { set_error("ltr_age_update: NULL argument"); return LTR_E_INVAL; }
+  return launch_age_update(ran, pri, idle, runs, N, (hipStream_t)stream);
+}
+
+int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int32_t N,
+                      int64_t token_budget, int64_t max_num_seqs, int32_t* n_selected_out, uint8_t* ran_out,
+                      int32_t* granted_out, void* stream) {
+  if (N < 0 || !n_selected_out || (N > 0 && (!perm || !new_tokens || !new_seqs))) {
+    set_error("ltr_budget_prefix: bad argument");
+    return LTR_E_INVAL;
+  }
+  return launch_budget_prefix(perm, new_tokens, new_seqs, N, token_budget, max_num_seqs, n_selected_out, ran_out,
+                              granted_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

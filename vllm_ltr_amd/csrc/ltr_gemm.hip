@@ -1,0 +1,276 @@
+// Dense layers of the predictor (QKV / out_proj / fc1 / fc2 / project_in) on gfx950 MFMA.
+//
+// Reference ops: QKVParallelLinear / RowParallelLinear / ColumnParallelLinear = F.linear
+// (vllm/model_executor/layers/linear.py), used by OPTAttention (opt.py:92-102) and
+// OPTDecoderLayer (opt.py:145-176).  C[M,N] = A[M,K] * W[N,K]^T (+bias)(ReLU)(+residual).
+//
+// Two arithmetic modes, selected by the checkpoint dtype:
+//  * F16 ("split") - the production path.  The checkpoint is fp16 (train/trainer.py:215),
+//    so W is exact in fp16.  Activations are carried as two fp16 planes a = hi + lo;
+//    acc += hi*W; acc += lo*W on v_mfma_f32_32x32x16_f16 with f32 accumulation.  That keeps
+//    ~22 significant bits of the f32 activation (score error vs the f32 CPU oracle ~4e-6,
+//    where plain fp16 activations give 2e-3), at 2 MFMA passes instead of the 16x slower
+//    f32 MFMA.
+//  * F32 - exact f32 MFMA (v_mfma_f32_32x32x2_f32) for f32 checkpoints / cross-checks.
+//
+// Tiling (both): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  Operands are staged
+// global -> registers -> LDS (next K-slab prefetched into registers while the current one
+// is multiplied).  LDS layouts are chosen per instruction so the fragment reads are
+// conflict-free (see lds_off_* below).  blockIdx is remapped so that consecutive tiles of
+// one XCD share the same weight panel (8 XCDs, private L2s).
+#include "ltr_internal.h"
+
+namespace ltr {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int NXCD = 8;
+
+// Workgroup -> tile map.  Hardware places block b on XCD b % 8.  Give each XCD a contiguous
+// run of tiles, walking M fastest inside a run so neighbours reuse the same W panel from
+// that XCD's L2 while the A panel streams.  Bijective for any grid size.
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg / NXCD, r = nwg % NXCD;
+  const int xcd = bid % NXCD, k = bid / NXCD;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  tm = lin % tiles_m;
+  tn = lin / tiles_m;
+}
+
+struct Epilogue {
+  const float* bias;
+  const float* resid;
+  float* out_f32;
+  void* out_hi;
+  void* out_lo;
+  int M, N, relu;
+};
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <bool SPLIT>
+__device__ __forceinline__ void store_tile(const Epilogue& e, const f32x16& acc, int row0, int col) {
+  if (col >= e.N) return;
+  const float b = e.bias ? e.bias[col] : 0.f;
+  const int lane_hi = (threadIdx.x & 63) >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lane_hi;
+    if (row < e.M) {
+      float v = acc[r] + b;
+      if (e.relu) v = fmaxf(v, 0.f);
+      const size_t o = (size_t)row * e.N + col;
+      if (e.resid) v += e.resid[o];
+      if (e.out_f32) e.out_f32[o] = v;
+      if (e.out_hi) {
+        if (SPLIT) {
+          __half h, l;
+          split_f16(v, h, l);
+          ((__half*)e.out_hi)[o] = h;
+          ((__half*)e.out_lo)[o] = l;
+        } else {
+          ((float*)e.out_hi)[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// F16 split mode.  K-slab = 32.  LDS tile [128 rows][32 halves] = 64 B rows, 16-byte
+// chunk kc of row r stored at chunk (kc ^ ((r >> 2) & 3)): a ds_read_b128 lane group
+// (16 lanes = rows {0-3,12-15,20-27} ...) then touches 16 distinct 16-B slots of the
+// 256-B bank row -> conflict-free (bank = (addr/4) % 64 for b128).
+// ------------------------------------------------------------------------------------
+constexpr int BK16 = 32;
+__device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
+  return row * BK16 + ((kc ^ ((row >> 2) & 3)) << 3);
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_f16s_kernel(
+    const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
+    int K, int tiles_m, int tiles_n, Epilogue ep) {
+  __shared__ __attribute__((aligned(16))) __half s_ahi[BM * BK16];
+  __shared__ __attribute__((aligned(16))) __half s_alo[BM * BK16];
+  __shared__ __attribute__((aligned(16))) __half s_w[BN * BK16];
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // staging map: chunk c = tid (+256): row = c >> 2, kc = c & 3
+  const int srow0 = tid >> 2, skc = tid & 3;
+  const int srow1 = srow0 + 64;
+  // clamp out-of-range rows to a valid row: their products land in rows/cols that the
+  // epilogue masks, so no zero fill is needed.
+  const size_t ga0 = (size_t)min(m0 + srow0, M - 1) * K + skc * 8;
+  const size_t ga1 = (size_t)min(m0 + srow1, M - 1) * K + skc * 8;
+  const size_t gw0 = (size_t)min(n0 + srow0, N - 1) * K + skc * 8;
+  const size_t gw1 = (size_t)min(n0 + srow1, N - 1) * K + skc * 8;
+  const int so0 = lds_off_h(srow0, skc), so1 = lds_off_h(srow1, skc);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 rh0, rh1, rl0, rl1, rw0, rw1;
+  auto gload = [&](int k0) {
+    rh0 = *reinterpret_cast<const uint4*>(a_hi + ga0 + k0);
+    rh1 = *reinterpret_cast<const uint4*>(a_hi + ga1 + k0);
+    rl0 = *reinterpret_cast<const uint4*>(a_lo + ga0 + k0);
+    rl1 = *reinterpret_cast<const uint4*>(a_lo + ga1 + k0);
+    rw0 = *reinterpret_cast<const uint4*>(w + gw0 + k0);
+    rw1 = *reinterpret_cast<const uint4*>(w + gw1 + k0);
+  };
+  gload(0);
+  const int frow = lane & 31, fk = lane >> 5;
+  for (int k0 = 0; k0 < K; k0 += BK16) {
+    __syncthreads();   // previous slab fully consumed
+    *reinterpret_cast<uint4*>(s_ahi + so0) = rh0;
+    *reinterpret_cast<uint4*>(s_ahi + so1) = rh1;
+    *reinterpret_cast<uint4*>(s_alo + so0) = rl0;
+    *reinterpret_cast<uint4*>(s_alo + so1) = rl1;
+    *reinterpret_cast<uint4*>(s_w + so0) = rw0;
+    *reinterpret_cast<uint4*>(s_w + so1) = rw1;
+    __syncthreads();
+    if (k0 + BK16 < K) gload(k0 + BK16);   // prefetch next slab under the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 2 + fk;
+      f16x8 ah[2], al[2], bw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wr * 64 + i * 32 + frow;
+        ah[i] = *reinterpret_cast<const f16x8*>(s_ahi + lds_off_h(row, kc));
+        al[i] = *reinterpret_cast<const f16x8*>(s_alo + lds_off_h(row, kc));
+        const int col = wc * 64 + i * 32 + frow;
+        bw[i] = *reinterpret_cast<const f16x8*>(s_w + lds_off_h(col, kc));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      store_tile<true>(ep, acc[i][j], m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32 + (lane & 31));
+}
+
+// ------------------------------------------------------------------------------------
+// F32 exact mode.  K-slab = 16, LDS holds the slab transposed [16 k][128 + 4 rows] so the
+// one-float-per-lane fragments of v_mfma_f32_32x32x2_f32 (lane l: row l&31, k = l>>5) are
+// stride-1 ds_read_b32 (conflict-free).
+// ------------------------------------------------------------------------------------
+constexpr int BK32 = 16;
+constexpr int LDT = BM + 4;
+
+__global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                         int M, int N, int K, int tiles_m, int tiles_n,
+                                                         Epilogue ep) {
+  __shared__ float s_a[BK32 * LDT];
+  __shared__ float s_w[BK32 * LDT];
+  int tm, tn;
+  tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int srow0 = tid >> 2, skq = tid & 3, srow1 = srow0 + 64;
+  const size_t ga0 = (size_t)min(m0 + srow0, M - 1) * K + skq * 4;
+  const size_t ga1 = (size_t)min(m0 + srow1, M - 1) * K + skq * 4;
+  const size_t gw0 = (size_t)min(n0 + srow0, N - 1) * K + skq * 4;
+  const size_t gw1 = (size_t)min(n0 + srow1, N - 1) * K + skq * 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra0, ra1, rw0, rw1;
+  auto gload = [&](int k0) {
+    ra0 = *reinterpret_cast<const float4*>(a + ga0 + k0);
+    ra1 = *reinterpret_cast<const float4*>(a + ga1 + k0);
+    rw0 = *reinterpret_cast<const float4*>(w + gw0 + k0);
+    rw1 = *reinterpret_cast<const float4*>(w + gw1 + k0);
+  };
+  auto sstore = [&](float* s, int row, const float4& v) {
+    s[(skq * 4 + 0) * LDT + row] = v.x;
+    s[(skq * 4 + 1) * LDT + row] = v.y;
+    s[(skq * 4 + 2) * LDT + row] = v.z;
+    s[(skq * 4 + 3) * LDT + row] = v.w;
+  };
+  gload(0);
+  const int frow = lane & 31, fk = lane >> 5;
+  for (int k0 = 0; k0 < K; k0 += BK32) {
+    __syncthreads();
+    sstore(s_a, srow0, ra0);
+    sstore(s_a, srow1, ra1);
+    sstore(s_w, srow0, rw0);
+    sstore(s_w, srow1, rw1);
+    __syncthreads();
+    if (k0 + BK32 < K) gload(k0 + BK32);
+#pragma unroll
+    for (int kk = 0; kk < BK32 / 2; ++kk) {
+      const int k = kk * 2 + fk;
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = s_a[k * LDT + wr * 64 + i * 32 + frow];
+        bv[i] = s_w[k * LDT + wc * 64 + i * 32 + frow];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      store_tile<false>(ep, acc[i][j], m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32 + (lane & 31));
+}
+
+}  // namespace
+
+int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
+  if (g.M == 0) return LTR_OK;
+  const int kmult = wdtype == LTR_W_F16 ? BK16 : BK32;
+  if (g.K % kmult) {
+    set_error("gemm: K=%d must be a multiple of %d", g.K, kmult);
+    return LTR_E_INVAL;
+  }
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu};
+  dim3 grid(tiles_m * tiles_n);
+  if (wdtype == LTR_W_F16) {
+    gemm_f16s_kernel<<<grid, 256, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
+                                          g.N, g.K, tiles_m, tiles_n, ep);
+  } else {
+    gemm_f32_kernel<<<grid, 256, 0, s>>>((const float*)g.a.hi, (const float*)g.w, g.M, g.N, g.K, tiles_m, tiles_n,
+                                         ep);
+  }
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+}  // namespace ltr

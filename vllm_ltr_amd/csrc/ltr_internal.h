@@ -1,0 +1,117 @@
+// Internal declarations shared by the HIP translation units of libltr_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, MFMA, 160 KiB LDS.  No other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/ltr_hip.h"
+
+namespace ltr {
+
+constexpr int WAVE = 64;
+constexpr float LN_EPS = 1e-5f;   // nn.LayerNorm default (opt.py:131-133)
+
+void set_error(const char* fmt, ...);
+
+#define LTR_HIP_CHECK(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      ::ltr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                       __FILE__, __LINE__);                                        \
+      return LTR_E_HIP;                                                            \
+    }                                                                              \
+  } while (0)
+
+#define LTR_LAUNCH_CHECK()                                                         \
+  do {                                                                             \
+    hipError_t _e = hipGetLastError();                                             \
+    if (_e != hipSuccess) {                                                        \
+      ::ltr::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),  \
+                       __FILE__, __LINE__);                                        \
+      return LTR_E_HIP;                                                            \
+    }                                                                              \
+  } while (0)
+
+// ---- activation operand of a GEMM ------------------------------------------------
+// F32 mode: `hi` is float [M, K], lo unused.
+// F16 mode: hi / lo are __half [M, K] planes with a = hi + lo (|lo| <= ulp(hi)/2), so
+// that a_hi*W + a_lo*W accumulated in f32 carries ~22 bits of the f32 activation.
+struct AOp {
+  void* hi;
+  void* lo;
+};
+
+enum OutKind { OUT_F32 = 1, OUT_SPLIT = 2 };
+
+struct GemmArgs {
+  AOp a;                 // [M, K]
+  const void* w;         // [N, K] row-major (nn.Linear layout), weight dtype
+  const float* bias;     // [N] or nullptr
+  const float* resid;    // f32 [M, N] or nullptr (may alias out_f32: in-place residual add)
+  float* out_f32;        // f32 [M, N] or nullptr
+  AOp out_split;         // hi/lo planes [M, N] (F16 mode) or f32 copy in .hi (F32 mode); may be null
+  int M, N, K;
+  int relu;
+};
+
+// launchers (each in its own .hip file)
+int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
+
+int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
+                     float* out_f32 /*nullable, may alias x*/, AOp out_op /*nullable*/, hipStream_t s);
+int launch_to_operand(int wdtype, const float* x, int64_t n, AOp out, hipStream_t s);
+
+int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N, int T, int tok_off,
+                        const void* tok_table, int De, int vocab, const void* pos_table, int H, int pos_rows,
+                        float* hidden_out, AOp tok_out /*only if De != H*/, hipStream_t s);
+
+// varlen causal attention over qkv f32 [T, 3H] (q | k | v, heads of 64), writes operand [T, H]
+int launch_attention(int wdtype, const float* qkv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req,
+                     int T, int H, int n_heads, int32_t* blk_start /*[n_req+1] scratch*/, AOp out,
+                     hipStream_t s);
+
+int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu, int tok_off, int N, int H, int De,
+                     int num_labels, const float* ln_w, const float* ln_b, const void* proj_out,
+                     const void* score_w, float* scores_out, float* logits_out, hipStream_t s);
+
+size_t rank_workspace_bytes(int64_t N);
+int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                     int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws, size_t ws_bytes,
+                     hipStream_t s);
+int launch_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int N, hipStream_t s);
+int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int N,
+                         int64_t token_budget, int64_t max_seqs, int32_t* n_sel, uint8_t* ran, int32_t* granted,
+                         hipStream_t s);
+
+// ---- device helpers ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// a = hi + lo with hi = fp16(a), lo = fp16(a - hi)
+__device__ __forceinline__ void split_f16(float a, __half& hi, __half& lo) {
+  hi = __float2half_rn(a);
+  lo = __float2half_rn(a - __half2float(hi));
+}
+
+// largest i in [0, n) with cu[i] <= t   (cu ascending, cu[0] <= t < cu[n])
+__device__ __forceinline__ int find_request(const int32_t* __restrict__ cu, int n, int t) {
+  int lo = 0, hi = n;  // answer in [lo, hi)
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (cu[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+}  // namespace ltr

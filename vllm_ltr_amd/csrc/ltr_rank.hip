@@ -1,0 +1,239 @@
+// Rank step of the scheduler queue on gfx950: starvation promote/demote, the stable
+// (pri, -score, tiebreak) sort, post-schedule aging, and the budget-walk prefix.
+//
+// Reference semantics: vllm/core/scheduler.py:984-998 (promote/demote + sorted()),
+// :1358-1365 (aging), :1137-1211 (budget walk `break` at first misfit).
+//
+// Sort design (integer/bit work, HBM/latency bound - no MFMA here):
+//   key64 = [pri bit | order-preserving u32 image of -score | 31-bit tiebreak]
+// Every key is unique (tiebreak is the input index by default), so the stable sort is a
+// plain sort of unique 64-bit keys and rank(i) = #{j : key_j < key_i} is a permutation.
+// For queue sizes on this path (1k..64k) a rank-by-counting sort fills all 256 CUs with
+// independent work and needs no inter-workgroup hand-off: each workgroup owns 64 keys,
+// streams a slice of the key array through LDS (coalesced 8-byte loads, broadcast
+// ds_read_b64), and counts.  Slices of j are spread over gridDim.y workgroups and merged
+// with one atomicAdd per key, so even an 8k queue launches >= 512 workgroups.
+#include "ltr_internal.h"
+
+namespace ltr {
+
+namespace {
+
+constexpr int RK_THREADS = 256;
+constexpr int RK_ITILE = 64;      // keys ranked per workgroup (one per lane)
+constexpr int RK_CHUNK = 1024;    // keys staged in LDS per iteration (8 KiB)
+
+__device__ __forceinline__ uint32_t float_order_bits(float x) {
+  uint32_t u = __float_as_uint(x);
+  if (u == 0x80000000u) u = 0u;                       // -0.0 == +0.0 (Python float compare)
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float -> ascending u32
+}
+
+// scheduler.py:986-993 + key build.  Also zeroes the rank accumulators.
+__global__ void __launch_bounds__(256) rank_prepare_kernel(
+    const float* __restrict__ score, int32_t* __restrict__ pri, int32_t* __restrict__ idle,
+    int32_t* __restrict__ runs, const uint32_t* __restrict__ tiebreak, int N, int starv, int period,
+    uint32_t flags, uint64_t* __restrict__ keys, int32_t* __restrict__ rank) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int p = 0;
+  if (pri != nullptr) {
+    p = pri[i];
+    if (starv != -1) {
+      int id = idle[i];
+      if (id >= starv) {
+        p = -1;
+        pri[i] = -1;
+        idle[i] = 0;
+        runs[i] = period;
+      } else if (p == -1 && runs[i] <= 0) {
+        p = 0;
+        pri[i] = 0;
+      }
+    }
+  }
+  float sc = score[i];
+  float k = (flags & LTR_RANK_ASCENDING) ? sc : -sc;
+  uint64_t pbit = 0;
+  if (flags & LTR_RANK_USE_PRI) pbit = (p < 0) ? 0ull : 1ull;   // pri in {-1, 0}: -1 first
+  uint32_t tb = tiebreak ? tiebreak[i] : (uint32_t)i;
+  keys[i] = (pbit << 63) | ((uint64_t)float_order_bits(k) << 31) | (uint64_t)(tb & 0x7fffffffu);
+  rank[i] = 0;
+}
+
+template <bool DIRECT>
+__global__ void __launch_bounds__(RK_THREADS) rank_count_kernel(
+    const uint64_t* __restrict__ keys, int N, int j_per_block, int32_t* __restrict__ rank,
+    int32_t* __restrict__ perm) {
+  __shared__ uint64_t skeys[RK_CHUNK];
+  __shared__ int32_t spart[RK_THREADS];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * RK_ITILE + lane;
+  const uint64_t ki = (i < N) ? keys[i] : 0ull;
+  const int jb = blockIdx.y * j_per_block;
+  const int je = min(N, jb + j_per_block);
+  int cnt = 0;
+  for (int j0 = jb; j0 < je; j0 += RK_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RK_CHUNK / RK_THREADS; ++r) {
+      int j = j0 + r * RK_THREADS + threadIdx.x;
+      skeys[r * RK_THREADS + threadIdx.x] = (j < je) ? keys[j] : ~0ull;  // pad: never < ki
+    }
+    __syncthreads();
+    const uint64_t* sk = skeys + wave * (RK_CHUNK / 4);
+#pragma unroll 16
+    for (int jj = 0; jj < RK_CHUNK / 4; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
+  }
+  spart[threadIdx.x] = cnt;
+  __syncthreads();
+  if (wave == 0 && i < N) {
+    int total = spart[lane] + spart[64 + lane] + spart[128 + lane] + spart[192 + lane];
+    if (DIRECT) perm[total] = i;
+    else atomicAdd(&rank[i], total);
+  }
+}
+
+__global__ void __launch_bounds__(256) rank_scatter_kernel(const int32_t* __restrict__ rank, int N,
+                                                           int32_t* __restrict__ perm) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) perm[rank[i]] = i;
+}
+
+// scheduler.py:1358-1365
+__global__ void __launch_bounds__(256) age_update_kernel(const uint8_t* __restrict__ ran,
+                                                         int32_t* __restrict__ pri, int32_t* __restrict__ idle,
+                                                         int32_t* __restrict__ runs, int N) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (ran[i]) {
+    if (pri[i] == -1) runs[i] -= 1;
+    idle[i] = 0;
+  } else {
+    idle[i] += 1;
+  }
+}
+
+// Budget-walk prefix (scheduler.py:1137-1211 with _get_num_new_tokens :1867-1888 and
+// SchedulingBudget.can_schedule :51-55).  With chunking on (the walk hard-codes
+// enable_chunking = True, :1128) a single-sequence request is granted
+// min(need, remaining_token_budget), so the walk selects request k (in ranked order) iff
+// for every j <= k:  need_j > 0, sum_{i<j} need_i < token_budget and
+// sum_{i<=j} seqs_i <= max_num_seqs; it breaks at the first k that fails.  Groups with
+// more than one sequence are not chunked and must fit whole.
+// Single workgroup, blocked scan over the ranked order.
+constexpr int BP_THREADS = 1024;
+__global__ void __launch_bounds__(BP_THREADS) budget_prefix_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ new_tokens,
+    const int32_t* __restrict__ new_seqs, int N, long long token_budget, long long max_seqs,
+    int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran, int32_t* __restrict__ granted) {
+  __shared__ long long s_tok[BP_THREADS / 64], s_seq[BP_THREADS / 64];
+  __shared__ long long carry_tok, carry_seq;
+  __shared__ int first_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { carry_tok = 0; carry_seq = 0; first_bad = N; }
+  __syncthreads();
+  for (int base = 0; base < N; base += BP_THREADS) {
+    int k = base + tid;
+    long long t = 0, q = 0;
+    int nt = 0, nq = 0, r = 0;
+    if (k < N) { r = perm[k]; nt = new_tokens[r]; nq = new_seqs[r]; t = nt; q = nq; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
+      long long tt = __shfl_up(t, o, 64), qq = __shfl_up(q, o, 64);
+      if (lane >= o) { t += tt; q += qq; }
+    }
+    if (lane == 63) { s_tok[wave] = t; s_seq[wave] = q; }
+    __syncthreads();
+    long long ot = carry_tok, oq = carry_seq;
+    for (int w = 0; w < wave; ++w) { ot += s_tok[w]; oq += s_seq[w]; }
+    t += ot; q += oq;
+    const long long before = t - nt;
+    bool bad = (k < N) && (nt == 0 || before >= token_budget || q > max_seqs ||
+                           (nq > 1 && t > token_budget));
+    if (bad) atomicMin(&first_bad, k);
+    if (k < N && granted != nullptr) {
+      long long g = token_budget - before;
+      granted[r] = (int)(g < nt ? (g > 0 ? g : 0) : nt);
+    }
+    __syncthreads();
+    if (tid == BP_THREADS - 1) { carry_tok = t; carry_seq = q; }
+    __syncthreads();
+    if (first_bad < N) break;   // uniform: read after the barrier
+  }
+  __syncthreads();
+  const int nsel = first_bad;
+  if (tid == 0) *n_sel = nsel;
+  for (int k = tid; k < N; k += BP_THREADS) {
+    int r = perm[k];
+    if (ran != nullptr) ran[r] = (k < nsel) ? 1 : 0;
+    if (granted != nullptr && k >= nsel) granted[r] = 0;
+  }
+}
+
+}  // namespace
+
+size_t rank_workspace_bytes(int64_t N) {
+  int64_t n = (N + 63) / 64 * 64;
+  return (size_t)(n * sizeof(uint64_t) + n * sizeof(int32_t) + 256);
+}
+
+int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                     int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
+  if (N == 0) return LTR_OK;
+  if (ws_bytes < rank_workspace_bytes(N)) {
+    set_error("ltr_rank_step: workspace %zu < %zu", ws_bytes, rank_workspace_bytes(N));
+    return LTR_E_NOMEM;
+  }
+  if (starv != -1) flags |= LTR_RANK_USE_PRI;           // scheduler.py:996 vs :998
+  if ((flags & LTR_RANK_USE_PRI) && pri == nullptr) {
+    set_error("ltr_rank_step: pri is NULL but the key uses it");
+    return LTR_E_INVAL;
+  }
+  if (starv != -1 && (idle == nullptr || runs == nullptr)) {
+    set_error("ltr_rank_step: starvation control needs idle and runs");
+    return LTR_E_INVAL;
+  }
+  int64_t n64 = ((int64_t)N + 63) / 64 * 64;
+  uint64_t* keys = (uint64_t*)ws;
+  int32_t* rank = (int32_t*)((char*)ws + n64 * sizeof(uint64_t));
+  rank_prepare_kernel<<<(N + 255) / 256, 256, 0, s>>>(scores, (flags & LTR_RANK_USE_PRI) ? pri : nullptr, idle,
+                                                      runs, tiebreak, N, starv, period, flags, keys, rank);
+  LTR_LAUNCH_CHECK();
+  const int itiles = (N + RK_ITILE - 1) / RK_ITILE;
+  // spread the j range so that the grid holds >= ~512 workgroups; slices are multiples of the chunk
+  int js = 1;
+  while (itiles * js < 512 && (int64_t)js * RK_CHUNK < N) js *= 2;
+  int j_per_block = (int)((((int64_t)N + js - 1) / js + RK_CHUNK - 1) / RK_CHUNK * RK_CHUNK);
+  js = (N + j_per_block - 1) / j_per_block;
+  if (js == 1) {
+    rank_count_kernel<true><<<dim3(itiles, 1), RK_THREADS, 0, s>>>(keys, N, j_per_block, rank, perm_out);
+    LTR_LAUNCH_CHECK();
+  } else {
+    rank_count_kernel<false><<<dim3(itiles, js), RK_THREADS, 0, s>>>(keys, N, j_per_block, rank, perm_out);
+    LTR_LAUNCH_CHECK();
+    rank_scatter_kernel<<<(N + 255) / 256, 256, 0, s>>>(rank, N, perm_out);
+    LTR_LAUNCH_CHECK();
+  }
+  return LTR_OK;
+}
+
+int launch_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int N, hipStream_t s) {
+  if (N == 0) return LTR_OK;
+  age_update_kernel<<<(N + 255) / 256, 256, 0, s>>>(ran, pri, idle, runs, N);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int N,
+                         int64_t token_budget, int64_t max_seqs, int32_t* n_sel, uint8_t* ran, int32_t* granted,
+                         hipStream_t s) {
+  budget_prefix_kernel<<<1, BP_THREADS, 0, s>>>(perm, new_tokens, new_seqs, N, (long long)token_budget,
+                                                (long long)max_seqs, n_sel, ran, granted);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+}  // namespace ltr

@@ -1,0 +1,205 @@
+// Row-wise HBM-bound kernels of the predictor forward on gfx950:
+//   * embedding gather    (opt.py:241-245, 43-53; vocab_parallel_embedding.py:95-106)
+//   * LayerNorm           (nn.LayerNorm in opt.py:131-133,165-167,222-224)
+//   * f32 -> GEMM operand (the hi|lo fp16 split of an activation)
+// One wave (64 lanes) owns one row; lanes walk the row in 16-byte pieces so every global
+// access is a full 1 KiB coalesced wave transaction.  No LDS is needed: the row lives in
+// registers and the two row moments come from wave shuffles.
+#include <algorithm>
+
+#include "ltr_internal.h"
+
+namespace ltr {
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 256 threads = 4 waves = 4 rows
+
+template <typename T> struct Vec8;   // 8 consecutive table elements -> 8 floats
+template <> struct Vec8<__half> {
+  static __device__ __forceinline__ void load(const __half* p, float (&v)[8]) {
+    uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const __half2* h = reinterpret_cast<const __half2*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float2 f = __half22float2(h[i]); v[2 * i] = f.x; v[2 * i + 1] = f.y; }
+  }
+};
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+
+__device__ __forceinline__ void store8_f32(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8_split(__half* hi, __half* lo, const float (&v)[8]) {
+  __half h[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split_f16(v[i], h[i], l[i]);
+  *reinterpret_cast<uint4*>(hi) = *reinterpret_cast<const uint4*>(h);
+  *reinterpret_cast<uint4*>(lo) = *reinterpret_cast<const uint4*>(l);
+}
+
+// hidden[t,:] = E_tok[ids[t],:] + E_pos[pos(t)+2,:]                      (De == H)
+// hidden[t,:] = E_pos[pos(t)+2,:];  tok_out[t,:] = E_tok[ids[t],:]       (De != H)
+template <typename WT, bool PROJ>
+__global__ void __launch_bounds__(256) embed_gather_kernel(
+    const int64_t* __restrict__ ids, const int32_t* __restrict__ cu, int n_req, int T, int tok_off,
+    const WT* __restrict__ tok_table, int De, int vocab, const WT* __restrict__ pos_table, int H,
+    int pos_rows, float* __restrict__ hidden, void* tok_hi, void* tok_lo) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);   // row inside this chunk
+  if (t >= T) return;
+  const int tg = tok_off + t;                                        // global token index
+  const int req = find_request(cu, n_req, tg);
+  int pos = tg - cu[req] + 2;                                        // opt.py:43-53 offset
+  pos = min(pos, pos_rows - 1);
+  long long id = ids[tg];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);                  // F.embedding would raise; clamp instead of faulting
+  const WT* trow = tok_table + (size_t)id * De;
+  const WT* prow = pos_table + (size_t)pos * H;
+  float* hrow = hidden + (size_t)t * H;
+  if (!PROJ) {
+    for (int c = lane * 8; c < H; c += 512) {
+      float a[8], b[8];
+      Vec8<WT>::load(trow + c, a);
+      Vec8<WT>::load(prow + c, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += b[i];
+      store8_f32(hrow + c, a);
+    }
+  } else {
+    for (int c = lane * 8; c < H; c += 512) {
+      float b[8];
+      Vec8<WT>::load(prow + c, b);
+      store8_f32(hrow + c, b);
+    }
+    for (int c = lane * 8; c < De; c += 512) {
+      float a[8];
+      Vec8<WT>::load(trow + c, a);
+      if (sizeof(WT) == 2) {
+        // table values are fp16 already: hi = value, lo = 0
+        store8_split((__half*)tok_hi + (size_t)t * De + c, (__half*)tok_lo + (size_t)t * De + c, a);
+      } else {
+        store8_f32((float*)tok_hi + (size_t)t * De + c, a);
+      }
+    }
+  }
+}
+
+// y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance, per row.
+// MAXV = ceil(H / 512) register chunks of 8 floats per lane.
+template <bool SPLIT, int MAXV>
+__global__ void __launch_bounds__(256) layernorm_kernel(
+    const float* x /* may alias out_f32 */, const float* __restrict__ gamma, const float* __restrict__ beta, int M,
+    int H, float* out_f32, void* out_hi, void* out_lo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * H;
+  float v[MAXV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int c = k * 512 + lane * 8;
+    if (c < H) {
+      Vec8<float>::load(xr + c, v[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[k][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int c = k * 512 + lane * 8;
+    if (c < H) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { float d = v[k][i] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + LN_EPS);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int c = k * 512 + lane * 8;
+    if (c < H) {
+      float g[8], b[8], y[8];
+      Vec8<float>::load(gamma + c, g);
+      Vec8<float>::load(beta + c, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = (v[k][i] - mean) * rstd * g[i] + b[i];
+      if (out_f32) store8_f32(out_f32 + (size_t)row * H + c, y);
+      if (out_hi) {
+        if (SPLIT) store8_split((__half*)out_hi + (size_t)row * H + c, (__half*)out_lo + (size_t)row * H + c, y);
+        else store8_f32((float*)out_hi + (size_t)row * H + c, y);
+      }
+    }
+  }
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) to_operand_kernel(const float* __restrict__ x, int64_t n8, void* hi,
+                                                         void* lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec8<float>::load(x + i * 8, v);
+    if (SPLIT) store8_split((__half*)hi + i * 8, (__half*)lo + i * 8, v);
+    else store8_f32((float*)hi + i * 8, v);
+  }
+}
+
+}  // namespace
+
+int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N, int T, int tok_off,
+                        const void* tok_table, int De, int vocab, const void* pos_table, int H, int pos_rows,
+                        float* hidden_out, AOp tok_out, hipStream_t s) {
+  if (T == 0) return LTR_OK;
+  if ((H % 8) || (De % 8)) { set_error("embed_gather: H and De must be multiples of 8"); return LTR_E_INVAL; }
+  dim3 grid((T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const bool proj = De != H;
+  if (wdtype == LTR_W_F16) {
+    if (proj) embed_gather_kernel<__half, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo);
+    else embed_gather_kernel<__half, false><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, nullptr, nullptr);
+  } else {
+    if (proj) embed_gather_kernel<float, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const float*)tok_table, De, vocab, (const float*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo);
+    else embed_gather_kernel<float, false><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const float*)tok_table, De, vocab, (const float*)pos_table, H, pos_rows, hidden_out, nullptr, nullptr);
+  }
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
+                     float* out_f32, AOp out_op, hipStream_t s) {
+  if (M == 0) return LTR_OK;
+  if (H % 8 || H > 2048) { set_error("layernorm: H must be a multiple of 8 and <= 2048"); return LTR_E_INVAL; }
+  dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const bool split = wdtype == LTR_W_F16;
+  const int maxv = (H + 511) / 512;
+#define LN_LAUNCH(SP, MV) layernorm_kernel<SP, MV><<<grid, 256, 0, s>>>(x, gamma, beta, M, H, out_f32, out_op.hi, out_op.lo)
+  if (split) {
+    if (maxv <= 1) LN_LAUNCH(true, 1); else if (maxv == 2) LN_LAUNCH(true, 2); else LN_LAUNCH(true, 4);
+  } else {
+    if (maxv <= 1) LN_LAUNCH(false, 1); else if (maxv == 2) LN_LAUNCH(false, 2); else LN_LAUNCH(false, 4);
+  }
+#undef LN_LAUNCH
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int launch_to_operand(int wdtype, const float* x, int64_t n, AOp out, hipStream_t s) {
+  if (n == 0) return LTR_OK;
+  if (n % 8) { set_error("to_operand: element count must be a multiple of 8"); return LTR_E_INVAL; }
+  int64_t n8 = n / 8;
+  int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 256 * 8);
+  if (wdtype == LTR_W_F16) to_operand_kernel<true><<<blocks, 256, 0, s>>>(x, n8, out.hi, out.lo);
+  else to_operand_kernel<false><<<blocks, 256, 0, s>>>(x, n8, out.hi, out.lo);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+}  // namespace ltr

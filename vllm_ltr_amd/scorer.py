@@ -1,0 +1,185 @@
+"""Device-side predictor: HF ``OPTForSequenceClassification`` weights resident in HBM,
+scored through ``ltr_score`` (libltr_hip.so).
+
+Mirrors what the reference's AUX engine does with the model
+(vllm/engine/aux_llm_engine.py:332-412 -> vllm/worker/model_runner.py:827-877 ->
+vllm/model_executor/models/opt.py:362-444) minus the second engine: one call scores a
+flat varlen batch of token ids.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .opt_spec import OPTSpec
+
+
+def _layer_names(i: int):
+    p = f"model.decoder.layers.{i}."
+    return p
+
+
+class HipOPTScorer:
+    """Owns the weight tensors (torch, device memory) and the ``ltr_handle``.
+
+    weight_dtype: "f16" (production: fp16 weights x hi+lo split activations, f32
+    accumulate) or "f32" (exact f32 MFMA path).
+    """
+
+    def __init__(self, spec: OPTSpec, ckpt: Dict[str, np.ndarray], device: str = "cuda:0",
+                 weight_dtype: str = "f16", chunk_tokens: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.LtrError("HipOPTScorer needs a ROCm GPU (no CPU fallback on the product path)")
+        self.lib = _lib.load()
+        self.spec = spec
+        self.device = torch.device(device)
+        self.weight_dtype = weight_dtype
+        wt = torch.float16 if weight_dtype == "f16" else torch.float32
+        self._tensors: List[Optional[torch.Tensor]] = []
+
+        def mat(name):        # matrices / tables in the weight dtype
+            return torch.from_numpy(np.ascontiguousarray(ckpt[name])).to(self.device, wt).contiguous()
+
+        def vec(name):        # biases / LN affine always f32
+            return torch.from_numpy(np.ascontiguousarray(ckpt[name]).astype(np.float32)).to(self.device).contiguous()
+
+        def cat(names, f):
+            return torch.cat([f(n) for n in names], 0).contiguous()
+
+        g: List[Optional[torch.Tensor]] = [
+            mat("model.decoder.embed_tokens.weight"),
+            mat("model.decoder.embed_positions.weight"),
+            mat("model.decoder.project_in.weight") if spec.has_proj else None,
+            mat("model.decoder.project_out.weight") if spec.has_proj else None,
+            vec("model.decoder.final_layer_norm.weight") if spec.has_final_ln else None,
+            vec("model.decoder.final_layer_norm.bias") if spec.has_final_ln else None,
+            mat("score.weight"),
+        ]
+        for i in range(spec.num_hidden_layers):
+            p = f"model.decoder.layers.{i}."
+            qkv = [p + f"self_attn.{x}_proj" for x in "qkv"]       # stacked q,k,v (opt.py:411-417)
+            g += [cat([n + ".weight" for n in qkv], mat), cat([n + ".bias" for n in qkv], vec),
+                  mat(p + "self_attn.out_proj.weight"), vec(p + "self_attn.out_proj.bias"),
+                  vec(p + "self_attn_layer_norm.weight"), vec(p + "self_attn_layer_norm.bias"),
+                  mat(p + "fc1.weight"), vec(p + "fc1.bias"), mat(p + "fc2.weight"), vec(p + "fc2.bias"),
+                  vec(p + "final_layer_norm.weight"), vec(p + "final_layer_norm.bias")]
+        self._tensors = g
+        ptrs = (C.c_void_p * len(g))(*[(t.data_ptr() if t is not None else None) for t in g])
+        desc = _lib.ModelDesc(spec.vocab_size, spec.hidden_size, spec.ffn_dim, spec.num_hidden_layers,
+                              spec.num_attention_heads, spec.word_embed_proj_dim,
+                              spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
+                              1 if spec.do_layer_norm_before else 0,
+                              _lib.LTR_W_F16 if weight_dtype == "f16" else _lib.LTR_W_F32)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), C.byref(self._h)), "ltr_create")
+        if chunk_tokens:
+            self.set_chunk_tokens(chunk_tokens)
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ltr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chunk_tokens(self, n: int):
+        _lib.check(self.lib.ltr_set_chunk_tokens(self._h, int(n)), "ltr_set_chunk_tokens")
+        self._ws = None
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, N: int, T: int) -> torch.Tensor:
+        need = int(self.lib.ltr_workspace_bytes(self._h, _lib.LTR_WS_SCORE, N, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @staticmethod
+    def pack(token_lists: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
+        """Flat ids + cu_seqlens, the layout ModelRunner._prepare_prompt builds
+        (model_runner.py:383-395, 711-716)."""
+        lens = np.fromiter((len(t) for t in token_lists), np.int64, len(token_lists))
+        cu = np.zeros(len(token_lists) + 1, np.int32)
+        np.cumsum(lens, out=cu[1:])
+        ids = np.empty(int(cu[-1]), np.int64)
+        for i, t in enumerate(token_lists):
+            ids[cu[i]:cu[i + 1]] = t
+        return ids, cu
+
+    # ------------------------------------------------------------------ calls
+    def score_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray,
+                     logits_out: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Inputs already resident in HBM (int64 [T], int32 [N+1]); returns f32 [N] on
+        the device.  ``cu_host`` is the host mirror of ``cu_dev``.  Asynchronous."""
+        N = int(cu_host.shape[0]) - 1
+        T = int(cu_host[-1]) if N >= 0 else 0
+        if out is None:
+            out = torch.empty(max(N, 0), dtype=torch.float32, device=self.device)
+        if N <= 0:
+            return out
+        assert ids_dev.dtype == torch.int64 and cu_dev.dtype == torch.int32
+        cu_host = np.ascontiguousarray(cu_host, dtype=np.int32)
+        ws = self._workspace(N, T)
+        max_len = int(np.diff(cu_host).max())
+        _lib.check(self.lib.ltr_score(self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), cu_host.ctypes.data, N, T,
+                                      max_len, out.data_ptr(),
+                                      logits_out.data_ptr() if logits_out is not None else None,
+                                      ws.data_ptr(), ws.numel(), self._stream()), "ltr_score")
+        return out
+
+    def score(self, ids: np.ndarray, cu_seqlens: np.ndarray, return_logits: bool = False):
+        """Host arrays in, host f32 scores out (synchronises)."""
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        N = cu.shape[0] - 1
+        if N <= 0:
+            z = np.zeros(0, np.float32)
+            return (z, np.zeros((0, self.spec.num_labels), np.float32)) if return_logits else z
+        ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+        cu_dev = torch.from_numpy(cu).to(self.device)
+        logits = torch.empty(N, self.spec.num_labels, dtype=torch.float32, device=self.device) \
+            if return_logits else None
+        s = self.score_device(ids_dev, cu_dev, cu, logits).cpu().numpy()
+        return (s, logits.cpu().numpy()) if return_logits else s
+
+    def score_lists(self, token_lists: Sequence[Sequence[int]]) -> np.ndarray:
+        ids, cu = self.pack(token_lists)
+        return self.score(ids, cu)
+
+    def hidden(self, ids: np.ndarray, cu_seqlens: np.ndarray, n_layers: int = -1) -> np.ndarray:
+        """f32 hidden states [T, H] after ``n_layers`` decoder layers (test hook)."""
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        N, T = cu.shape[0] - 1, int(cu[-1])
+        ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+        cu_dev = torch.from_numpy(cu).to(self.device)
+        out = torch.empty(T, self.spec.hidden_size, dtype=torch.float32, device=self.device)
+        ws = self._workspace(N, T)
+        _lib.check(self.lib.ltr_forward_hidden(self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), cu.ctypes.data, N, T,
+                                               int(np.diff(cu).max()), n_layers, out.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), self._stream()), "ltr_forward_hidden")
+        return out.cpu().numpy()
+
+    def embed_gather_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, N: int, T: int,
+                            hidden_out: torch.Tensor, tok_out: Optional[torch.Tensor] = None) -> None:
+        _lib.check(self.lib.ltr_embed_gather(self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), N, T,
+                                             hidden_out.data_ptr(),
+                                             tok_out.data_ptr() if tok_out is not None else None,
+                                             self._stream()), "ltr_embed_gather")
+
+    def pool_head_device(self, hidden: torch.Tensor, cu_dev: torch.Tensor, N: int, scores_out: torch.Tensor,
+                         logits_out: Optional[torch.Tensor] = None) -> None:
+        _lib.check(self.lib.ltr_pool_head(self._h, hidden.data_ptr(), cu_dev.data_ptr(), N, scores_out.data_ptr(),
+                                          logits_out.data_ptr() if logits_out is not None else None,
+                                          self._stream()), "ltr_pool_head")
