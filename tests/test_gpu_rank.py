@@ -57,7 +57,7 @@ def test_golden_order_cases(dev):
                                             (1000, 200, 10), (1025, 2, 2), (8192, 200, 10), (8192, -1, 0),
                                             (20000, 7, 3), (65536, 200, 10), (100003, -1, 0)])
 def test_rank_step_vs_oracle(dev, n, starv, period):
-    r = np.random.RandomState(n + 7 * starv)
+    r = np.random.RandomState(n + 7 * (starv + 1))
     score = r.standard_normal(n).astype(np.float32).astype(np.float16).astype(np.float32)   # many ties
     score[r.randint(0, n, max(1, n // 20))] = 0.0
     score[r.randint(0, n, max(1, n // 20))] = -0.0

@@ -257,7 +257,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
   const ltr_model_desc& d = h->d;
   const int max_pos = d.pos_rows - 2;
   // chunk budget from the workspace actually provided
-  int64_t Tc_cap = chunk_cap(h);
+  int64_t Tc_cap = chunk_cap(h) < T ? chunk_cap(h) : T;
   while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr).bytes > ws_bytes) Tc_cap /= 2;
   int r0 = 0;
   while (r0 < N) {
