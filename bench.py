@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the ranking hot path (BASELINE.json):
+
+    requests ranked/sec + p50 rank latency, 8k waiting queue, OPT-125m predictor.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one COLD ranker call on the synthetic queue (every request unscored):
+predictor forward over all prompts (ltr_score) -> [N>1: RCCL all-gather of the score
+shards] -> starvation promote/demote + priority sort (ltr_rank_step) -> budget-walk
+prefix (ltr_budget_prefix) -> aging (ltr_age_update).  Inputs (token ids, cu_seqlens,
+queue state) are resident in HBM before the timed region.  N>1 is weak scaling: every
+rank scores its own 8k-request shard of an N*8k queue (BASELINE config 4 at N=8) and all
+ranks rank the whole gathered queue.
+
+Rank 0 prints one JSON line (contract in the task statement) with `roofline` for the
+dominant kernel and `cpu_baseline` (the oracle = CPU restatement of the reference, timed
+on this host on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint  # noqa: E402
+
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+
+def synthetic_queue(spec: OPTSpec, n: int, seed: int):
+    """BASELINE.md section 4 / SURVEY.md 8d: lengths clip(rint(exp(N(ln 64, 0.8))), 4, 1024);
+    ids [2] + randint(4, vocab)."""
+    rs = np.random.RandomState(seed)
+    lens = np.clip(np.rint(np.exp(rs.normal(np.log(64.0), 0.8, n))), 4, 1024).astype(np.int64)
+    g = torch.Generator().manual_seed(seed)
+    T = int(lens.sum())
+    ids = torch.randint(4, spec.vocab_size, (T,), generator=g, dtype=torch.int64).numpy()
+    cu = np.zeros(n + 1, np.int32)
+    np.cumsum(lens, out=cu[1:])
+    ids[cu[:-1]] = 2
+    return ids, cu, lens
+
+
+def model_flops(spec: OPTSpec, lens: np.ndarray):
+    """SURVEY.md 8d algorithmic FLOPs of the decoder stack: Nl*[2L(4H^2+2HF) + 2L^2 H]."""
+    H, F, Nl = spec.hidden_size, spec.ffn_dim, spec.num_hidden_layers
+    L = lens.astype(np.float64)
+    lin = Nl * 2.0 * (4 * H * H + 2 * H * F) * L.sum()
+    if spec.has_proj:
+        lin += 4.0 * spec.word_embed_proj_dim * H * L.sum()
+    att = Nl * 2.0 * H * (L * L).sum()
+    return lin, att
+
+
+def cpu_baseline(spec, ckpt, ids, cu, starv, period, budget_s: float = 12.0):
+    """The oracle (CPU restatement of the reference path, oracle/) timed on this host's
+    cores on a bounded prefix of the same workload: fp32 torch predictor packed <= 2048
+    tokens per forward like the AUX engine (config.py:578-586) + the literal Python
+    promote/demote + sorted() + aging."""
+    from oracle import rank_step as rs
+    from oracle.opt_scorer import OracleOPTScorer
+    # threads actually used: the affinity mask, capped - beyond ~32 threads the small
+    # per-forward GEMMs ([<=2048, 768] x [768, 3072]) stop scaling and oversubscribed
+    # hosts collapse (measured: 256 threads on the GPU box = 13 s per request)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
+    torch.set_num_threads(cores)
+    orc = OracleOPTScorer(spec, ckpt)
+    orc.score_packed(ids[:cu[2]], cu[:3])                      # warm-up (thread pool, allocator)
+    n0 = 8
+    t = time.perf_counter()
+    orc.score_packed(ids[:cu[n0]], cu[:n0 + 1])
+    dt = time.perf_counter() - t
+    n = int(min(len(cu) - 1, max(n0, n0 * budget_s / max(dt, 1e-3))))
+    t = time.perf_counter()
+    scores = orc.score_packed(ids[:cu[n]], cu[:n + 1])
+    t_score = time.perf_counter() - t
+    reqs = [rs.Req(str(i), float(s)) for i, s in enumerate(scores)]
+    t = time.perf_counter()
+    order = rs.opt_order(reqs, starv, period)
+    rs.age_update(reqs, order[:256])
+    t_rank = time.perf_counter() - t
+    return dict(value=n / (t_score + t_rank), unit="requests/s", cores=cores, kind="port",
+                sample=f"first {n} requests of the same queue ({int(cu[n])} tokens): oracle fp32 torch "
+                       f"forward packed<=2048 tok ({t_score:.2f}s) + literal Python rank/age ({t_rank*1e3:.2f}ms)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--queue", type=int, default=8192, help="requests per GPU")
+    ap.add_argument("--model", default="125m", choices=["125m", "350m"])
+    ap.add_argument("--weight-dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--chunk-tokens", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--starv", type=int, default=200)
+    ap.add_argument("--period", type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vllm_ltr_amd.rank import DeviceQueue, budget_prefix
+    from vllm_ltr_amd.scorer import HipOPTScorer
+
+    spec = OPTSpec.opt_125m() if args.model == "125m" else OPTSpec.opt_350m()
+    ckpt = seeded_checkpoint(spec, 0)
+    scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)
+
+    # this rank's shard of the queue (weak scaling: args.queue requests per GPU)
+    n_local = args.queue
+    n_total = n_local * world
+    ids, cu, lens = synthetic_queue(spec, n_local, seed=rank)
+    ids_d = torch.from_numpy(ids).to(dev)
+    cu_d = torch.from_numpy(cu).to(dev)
+    shard_scores = torch.empty(n_local, dtype=torch.float32, device=dev)
+    all_scores = torch.empty(n_total, dtype=torch.float32, device=dev)
+    queue = DeviceQueue(dev, starv=args.starv, period=args.period, capacity=n_total)
+    queue.append(torch.zeros(n_total))
+    need_tokens = torch.from_numpy(np.tile(lens, world).astype(np.int32)).to(dev)
+    need_seqs = torch.ones(n_total, dtype=torch.int32, device=dev)
+    perm = torch.empty(n_total, dtype=torch.int32, device=dev)
+
+    def step():
+        scorer.score_device(ids_d, cu_d, cu, out=shard_scores)
+        if world > 1:
+            dist.all_gather_into_tensor(all_scores, shard_scores)
+            queue._score[:n_total].copy_(all_scores)
+        else:
+            queue._score[:n_total].copy_(shard_scores)
+        queue.rank(out=perm)
+        _, ran, _ = budget_prefix(perm, need_tokens, need_seqs, 2048, 256, want_granted=False)
+        queue.age(ran)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    scorer.profile(True)
+    scorer.profile_read(reset=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = scorer.profile_read(reset=True)
+    scorer.profile(False)
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    # rank-only latency (steady call with nothing new to score), measured outside the timed region
+    rk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in rk:
+        a.record()
+        queue.rank(out=perm)
+        _, ran, _ = budget_prefix(perm, need_tokens, need_seqs, 2048, 256, want_granted=False)
+        queue.age(ran)
+        b.record()
+    torch.cuda.synchronize()
+    rank_ms = sorted(a.elapsed_time(b) for a, b in rk)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        lin, att = model_flops(spec, lens)
+        gemm = prof["gemm"]
+        gemm_tflops = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
+        kernels = {}
+        for k, v in prof.items():
+            if v["launches"] == 0:
+                continue
+            rate = v["work"] / (v["ms"] * 1e-3)
+            if k in ("gemm", "attn"):
+                kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
+                                  tflops=rate / 1e12)
+            else:
+                kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
+                                  gbs=rate / 1e9, frac_hbm=rate / 1e9 / PEAK_HBM_GBS)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "requests ranked/sec (cold call: OPT predictor forward + priority sort/aging)",
+            "value": n_total * args.steps / elapsed,
+            "unit": "requests/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "p50_rank_latency_ms": step_ms[len(step_ms) // 2],
+            "p50_steady_rank_latency_ms": rank_ms[len(rank_ms) // 2],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if args.weight_dtype == "f16" else "f32",
+            "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths, random token ids)",
+            "config": {"workload": f"OPT-{args.model} predictor, {n_local} synthetic queue per GPU "
+                                   f"({n_total} total), cold ranker call", "queue_per_gpu": n_local,
+                       "tokens_per_gpu": int(cu[-1]), "starv": args.starv, "period": args.period,
+                       "parallelism": f"request-sharded dp{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16s_kernel" if args.weight_dtype == "f16" else "gemm_f32_kernel",
+                         "achieved": gemm_tflops, "peak": PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3,
+                         "unit": "TFLOP/s", "frac": gemm_tflops / (PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3),
+                         "traffic": traffic,
+                         "launches_per_step": gemm["launches"] // max(args.steps, 1),
+                         "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1)},
+            "kernels": kernels,
+            "model_tflop_per_step": (lin + att) / 1e12,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, ckpt, ids, cu, args.starv, args.period)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,21 @@ int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* run
 int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int32_t N,
                    void* stream);
 
+/* Per-kernel-class timing for the roofline report (bench.py).  When enabled, ltr_score /
+ * ltr_forward_hidden bracket every launch with HIP events on the caller's stream (no host
+ * sync); ltr_profile_read synchronises on the last event, sums event-to-event durations
+ * per class and optionally resets.  work = algorithmic FLOPs (GEMM: 2*M*N*K; ATTN: causal
+ * 2*L^2*H per layer and request) or algorithmic bytes (EMBED, LN, POOL) as defined in
+ * DESIGN.md. */
+enum { LTR_K_GEMM = 0, LTR_K_ATTN = 1, LTR_K_EMBED = 2, LTR_K_LN = 3, LTR_K_POOL = 4, LTR_K_COUNT = 5 };
+typedef struct ltr_profile_stats {
+  double ms[8];        /* summed kernel time per class   */
+  double work[8];      /* summed algorithmic FLOPs/bytes */
+  int64_t launches[8];
+} ltr_profile_stats;
+int ltr_profile_enable(ltr_handle h, int32_t on);
+int ltr_profile_read(ltr_handle h, ltr_profile_stats* out, int32_t reset);
+
 /* Next row in scope: the selection the budget walk of
  * Scheduler._general_schedule makes over the ranked order (scheduler.py:1137-1211, with
  * _get_num_new_tokens :1867-1888 and SchedulingBudget.can_schedule :51-55), as one scan:

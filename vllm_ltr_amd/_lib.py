@@ -20,7 +20,7 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 # every symbol include/ltr_hip.h declares (tests check the library exports them all)
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
            "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
-           "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix")
+           "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read")
 
 
 class LtrError(RuntimeError):
@@ -32,6 +32,12 @@ class ModelDesc(C.Structure):
         "vocab_size", "hidden_size", "ffn_dim", "num_layers", "num_heads", "word_embed_proj_dim",
         "pos_rows", "num_labels", "pre_ln", "weight_dtype")]
 
+
+class ProfileStats(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("work", C.c_double * 8), ("launches", C.c_int64 * 8)]
+
+
+PROFILE_KINDS = ("gemm", "attn", "embed", "ln", "pool")
 
 _lib = None
 
@@ -60,6 +66,8 @@ def load() -> C.CDLL:
     lib.ltr_rank_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, sz, vp]
     lib.ltr_age_update.argtypes = [vp, vp, vp, vp, i32, vp]
     lib.ltr_budget_prefix.argtypes = [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp]
+    lib.ltr_profile_enable.argtypes = [vp, i32]
+    lib.ltr_profile_read.argtypes = [vp, C.POINTER(ProfileStats), i32]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version"):

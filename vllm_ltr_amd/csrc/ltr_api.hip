@@ -29,10 +29,23 @@ void set_error(const char* fmt, ...) {
 
 using namespace ltr;
 
+struct ProfRec {
+  hipEvent_t start, stop;
+  int kind;
+  double work;
+};
+
 struct ltr_model {
   ltr_model_desc d;
   std::vector<const void*> w;
   int chunk_tokens;
+  bool prof_on = false;
+  std::vector<ProfRec> prof;       // records in use
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+  ~ltr_model() {
+    for (auto& r : prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    for (auto& e : prof_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
   const void* gw(int i) const { return w[i]; }
   const void* lw(int layer, int i) const { return w[LTR_WT_GLOBAL_COUNT + layer * LTR_WL_COUNT + i]; }
 };
@@ -76,23 +89,57 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base) {
   return ws;
 }
 
+// Brackets one launch with events when profiling is on (no host sync).
+struct ProfScope {
+  ltr_model* m;
+  hipStream_t s;
+  int idx = -1;
+  ProfScope(const ltr_model* cm, int kind, double work, hipStream_t st) : m(const_cast<ltr_model*>(cm)), s(st) {
+    if (!m->prof_on) return;
+    ProfRec r{};
+    if (!m->prof_free.empty()) {
+      r.start = m->prof_free.back().first; r.stop = m->prof_free.back().second; m->prof_free.pop_back();
+    } else if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+      return;
+    }
+    r.kind = kind; r.work = work;
+    (void)hipEventRecord(r.start, s);
+    m->prof.push_back(r);
+    idx = (int)m->prof.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(m->prof[idx].stop, s); }
+};
+
 // one request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch
 int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev, int N_total, int r0, int r1, int t0,
-                  int t1, int n_layers, const Workspace& ws, hipStream_t s) {
+                  int t1, int n_layers, const Workspace& ws, double sum_l2, hipStream_t s) {
   const ltr_model_desc& d = m->d;
   const int wd = d.weight_dtype;
   const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim;
   const int Tc = t1 - t0, nreq = r1 - r0;
   int rc;
   // --- embedding (opt.py:241-245)
-  rc = launch_embed_gather(wd, ids, cu_dev, N_total, Tc, t0, m->gw(LTR_WT_EMBED_TOKENS), De, d.vocab_size,
-                           m->gw(LTR_WT_EMBED_POS), H, d.pos_rows, ws.h, ws.a, s);
+  const double wbytes = wd == LTR_W_F16 ? 2.0 : 4.0;
+  const double ln_bytes = (double)Tc * H * 8.0;   // read f32 row + write operand row (4 B/elem)
+  auto gemm = [&](const GemmArgs& g) {
+    ProfScope p(m, LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
+    return launch_gemm(wd, g, s);
+  };
+  auto lnorm = [&](const float* x, const float* gw_, const float* gb_, float* of, AOp oo) {
+    ProfScope p(m, LTR_K_LN, ln_bytes + (of ? (double)Tc * H * 4.0 : 0.0), s);
+    return launch_layernorm(wd, x, gw_, gb_, Tc, H, of, oo, s);
+  };
+  {
+    ProfScope p(m, LTR_K_EMBED, (double)Tc * (8.0 + (De + H) * wbytes + H * 4.0), s);
+    rc = launch_embed_gather(wd, ids, cu_dev, N_total, Tc, t0, m->gw(LTR_WT_EMBED_TOKENS), De, d.vocab_size,
+                             m->gw(LTR_WT_EMBED_POS), H, d.pos_rows, ws.h, ws.a, s);
+  }
   if (rc) return rc;
   if (De != H) {   // h = project_in(tok) + pos : GEMM with the position rows as residual (in place)
     GemmArgs g{};
     g.a = ws.a; g.w = m->gw(LTR_WT_PROJECT_IN); g.bias = nullptr; g.resid = ws.h; g.out_f32 = ws.h;
     g.M = Tc; g.N = H; g.K = De;
-    if ((rc = launch_gemm(wd, g, s))) return rc;
+    if ((rc = gemm(g))) return rc;
   }
   if (!d.pre_ln) {   // post-LN blocks consume h itself as the first GEMM operand
     if ((rc = launch_to_operand(wd, ws.h, (int64_t)Tc * H, ws.a, s))) return rc;
@@ -101,50 +148,49 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   for (int L = 0; L < nl; ++L) {
     // --- attention half (opt.py:152-163)
     if (d.pre_ln) {
-      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), Tc,
-                            H, nullptr, ws.a, s);
+      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ws.a);
       if (rc) return rc;
     }
     {
       GemmArgs g{};
       g.a = ws.a; g.w = m->lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
       g.out_f32 = ws.qkv; g.M = Tc; g.N = 3 * H; g.K = H;
-      if ((rc = launch_gemm(wd, g, s))) return rc;
+      if ((rc = gemm(g))) return rc;
     }
-    rc = launch_attention(wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads, ws.blk, ws.a, s);
+    {
+      ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
+      rc = launch_attention(wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads, ws.blk, ws.a, s);
+    }
     if (rc) return rc;
     {
       GemmArgs g{};
       g.a = ws.a; g.w = m->lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = ws.h; g.out_f32 = ws.h; g.M = Tc; g.N = H; g.K = H;
-      if ((rc = launch_gemm(wd, g, s))) return rc;
+      if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {   // 350m: LN after the residual add; h and its operand copy
-      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), Tc,
-                            H, ws.h, ws.a, s);
+      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), ws.h, ws.a);
       if (rc) return rc;
     }
     // --- feed-forward half (opt.py:165-175)
     if (d.pre_ln) {
-      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), Tc,
-                            H, nullptr, ws.a, s);
+      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), nullptr, ws.a);
       if (rc) return rc;
     }
     {
       GemmArgs g{};
       g.a = ws.a; g.w = m->lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
       g.out_split = ws.f; g.relu = 1; g.M = Tc; g.N = F; g.K = H;
-      if ((rc = launch_gemm(wd, g, s))) return rc;
+      if ((rc = gemm(g))) return rc;
     }
     {
       GemmArgs g{};
       g.a = ws.f; g.w = m->lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = ws.h; g.out_f32 = ws.h; g.M = Tc; g.N = H; g.K = F;
-      if ((rc = launch_gemm(wd, g, s))) return rc;
+      if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {
-      rc = launch_layernorm(wd, ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), Tc,
-                            H, ws.h, ws.a, s);
+      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), ws.h, ws.a);
       if (rc) return rc;
     }
   }
@@ -278,11 +324,14 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     Workspace ws = carve(d, t1 - t0, r1 - r0, workspace);
     if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
     if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
-    rc = forward_chunk(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, s);
+    double sum_l2 = 0.0;
+    for (int r = r0; r < r1; ++r) { const double L = cu[r + 1] - cu[r]; sum_l2 += L * L; }
+    rc = forward_chunk(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, sum_l2, s);
     if (rc) return rc;
     if (hidden_out) {
       LTR_HIP_CHECK(hipMemcpyAsync(hidden_out, ws.h, (size_t)(t1 - t0) * d.hidden_size * 4, hipMemcpyDeviceToDevice, s));
     } else {
+      ProfScope p(h, LTR_K_POOL, (double)(r1 - r0) * (d.hidden_size * 4.0 + 4.0), s);
       rc = launch_pool_head(d.weight_dtype, ws.h, cu_seqlens + r0, t0, r1 - r0, d.hidden_size, d.word_embed_proj_dim,
                             d.num_labels, (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
                             d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
@@ -350,6 +399,30 @@ int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* run
   if (N == 0) return LTR_OK;
   if (!ran || !pri || !idle || !runs) { set_error("ltr_age_update: NULL argument"); return LTR_E_INVAL; }
   return launch_age_update(ran, pri, idle, runs, N, (hipStream_t)stream);
+}
+
+int ltr_profile_enable(ltr_handle h, int32_t on) {
+  if (!h) { set_error("ltr_profile_enable: NULL handle"); return LTR_E_INVAL; }
+  h->prof_on = on != 0;
+  return LTR_OK;
+}
+
+int ltr_profile_read(ltr_handle h, ltr_profile_stats* out, int32_t reset) {
+  if (!h || !out) { set_error("ltr_profile_read: NULL argument"); return LTR_E_INVAL; }
+  memset(out, 0, sizeof(*out));
+  for (auto& r : h->prof) {
+    LTR_HIP_CHECK(hipEventSynchronize(r.stop));
+    float ms = 0.f;
+    LTR_HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
+    out->ms[r.kind] += ms;
+    out->work[r.kind] += r.work;
+    out->launches[r.kind] += 1;
+  }
+  if (reset) {
+    for (auto& r : h->prof) h->prof_free.emplace_back(r.start, r.stop);
+    h->prof.clear();
+  }
+  return LTR_OK;
 }
 
 int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int32_t N,

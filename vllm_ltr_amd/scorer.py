@@ -95,6 +95,16 @@ class HipOPTScorer:
         _lib.check(self.lib.ltr_set_chunk_tokens(self._h, int(n)), "ltr_set_chunk_tokens")
         self._ws = None
 
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.ltr_profile_enable(self._h, 1 if on else 0), "ltr_profile_enable")
+
+    def profile_read(self, reset: bool = True) -> dict:
+        """Per-kernel-class {ms, work, launches} since the last reset (synchronises)."""
+        st = _lib.ProfileStats()
+        _lib.check(self.lib.ltr_profile_read(self._h, C.byref(st), 1 if reset else 0), "ltr_profile_read")
+        return {k: dict(ms=st.ms[i], work=st.work[i], launches=int(st.launches[i]))
+                for i, k in enumerate(_lib.PROFILE_KINDS)}
+
     # ------------------------------------------------------------------ helpers
     def _workspace(self, N: int, T: int) -> torch.Tensor:
         need = int(self.lib.ltr_workspace_bytes(self._h, _lib.LTR_WS_SCORE, N, T))
