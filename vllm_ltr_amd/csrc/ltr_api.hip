@@ -8,6 +8,7 @@
 // (vllm/worker/model_runner.py:827-877) -> OPTForSequenceClassification (opt.py:378-409).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -40,6 +41,7 @@ struct ltr_model {
   std::vector<const void*> w;
   int chunk_tokens;
   bool prof_on = false;
+  bool dbg_attn_valu = false;   // LTR_DEBUG_ATTN_VALU=1: f32 VALU attention inside the F16 mode (A/B for accuracy work)
   std::vector<ProfRec> prof;       // records in use
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
   ~ltr_model() {
@@ -60,7 +62,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct Workspace {
   float* h;        // f32 [Tc, H]      residual stream
   AOp a;           // operand [Tc, H]  LN out / attention out / (De!=H: token rows)
-  float* qkv;      // f32 [Tc, 3H]
+  AOp qkv;         // [Tc, 3H]: f32 (F32 mode) or fp16 hi|lo planes written by the QKV GEMM epilogue
   AOp f;           // operand [Tc, F]  ReLU(fc1)
   int32_t* blk;    // int32 [Nc + 1]
   size_t bytes;
@@ -75,15 +77,17 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base) {
   auto take = [&](size_t n) { size_t o = off; off += align_up(n); return base ? (void*)(p + o) : (void*)nullptr; };
   ws.h = (float*)take(Tc * H * 4);
   char* a = (char*)take(Tc * H * esz);
-  ws.qkv = (float*)take(Tc * 3 * H * 4);
+  char* qkv = (char*)take(Tc * 3 * H * esz);
   char* f = (char*)take(Tc * F * esz);
   ws.blk = (int32_t*)take((Nc + 1) * 4);
   if (d.weight_dtype == LTR_W_F16) {
     ws.a = AOp{a, a ? a + Tc * H * 2 : nullptr};
     ws.f = AOp{f, f ? f + Tc * F * 2 : nullptr};
+    ws.qkv = AOp{qkv, qkv ? qkv + Tc * 3 * H * 2 : nullptr};
   } else {
     ws.a = AOp{a, nullptr};
     ws.f = AOp{f, nullptr};
+    ws.qkv = AOp{qkv, nullptr};
   }
   ws.bytes = off;
   return ws;
@@ -154,12 +158,14 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     {
       GemmArgs g{};
       g.a = ws.a; g.w = m->lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
-      g.out_f32 = ws.qkv; g.M = Tc; g.N = 3 * H; g.K = H;
+      if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
+      g.M = Tc; g.N = 3 * H; g.K = H;
       if ((rc = gemm(g))) return rc;
     }
     {
       ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
-      rc = launch_attention(wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads, ws.blk, ws.a, s);
+      rc = launch_attention(m->dbg_attn_valu && wd == LTR_W_F16 ? -1 : wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads,
+                            ws.blk, ws.a, s);
     }
     if (rc) return rc;
     {
@@ -263,6 +269,7 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
   m->d = *desc;
   m->w.assign(weights, weights + want);
   m->chunk_tokens = DEFAULT_CHUNK_TOKENS;
+  { const char* e = getenv("LTR_DEBUG_ATTN_VALU"); m->dbg_attn_valu = e && e[0] == '1'; }
   *out = m;
   return LTR_OK;
 }

@@ -68,8 +68,9 @@ int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N
                         const void* tok_table, int De, int vocab, const void* pos_table, int H, int pos_rows,
                         float* hidden_out, AOp tok_out /*only if De != H*/, hipStream_t s);
 
-// varlen causal attention over qkv f32 [T, 3H] (q | k | v, heads of 64), writes operand [T, H]
-int launch_attention(int wdtype, const float* qkv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req,
+// varlen causal attention over qkv [T, 3H] (q | k | v, heads of 64; f32, or fp16 hi|lo planes
+// in the F16 mode), writes operand [T, H]
+int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req,
                      int T, int H, int n_heads, int32_t* blk_start /*[n_req+1] scratch*/, AOp out,
                      hipStream_t s);
 
@@ -98,8 +99,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// a = hi + lo with hi = fp16(a), lo = fp16(a - hi)
+// a = hi + lo with hi = fp16(a), lo = fp16(a - hi).
+// The empty asm pins `a` as one materialised f32 value: without it, when `a` is a product
+// x*y, hipcc contracts `a - hi` into v_fma_mix(x, y, -hi) (exact product) while the stored
+// hi comes from the f32-ROUNDED product, and in near-tie cases the two disagree by one
+// fp16 ulp with the wrong-signed lo (measured: isolated 2^-12 errors in the attention output).
 __device__ __forceinline__ void split_f16(float a, __half& hi, __half& lo) {
+  asm volatile("" : "+v"(a));
   hi = __float2half_rn(a);
   lo = __float2half_rn(a - __half2float(hi));
 }
