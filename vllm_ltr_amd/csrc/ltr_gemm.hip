@@ -14,11 +14,11 @@
 //  * F32 - exact f32 MFMA (v_mfma_f32_32x32x2_f32) for f32 checkpoints / cross-checks.
 //
 // Tiling (both): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave a
-// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  Operands are staged
-// global -> registers -> LDS (next K-slab prefetched into registers while the current one
-// is multiplied).  LDS layouts are chosen per instruction so the fragment reads are
-// conflict-free (see lds_off_* below).  blockIdx is remapped so that consecutive tiles of
-// one XCD share the same weight panel (8 XCDs, private L2s).
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  LDS layouts are chosen per
+// instruction so the fragment reads are conflict-free (see lds_off_* below).  blockIdx is
+// remapped so that consecutive tiles of one XCD share the same weight panel (8 XCDs,
+// private L2s).  The F16 kernel streams operands HBM -> LDS with global_load_lds; the F32
+// kernel stages through registers.
 #include "ltr_internal.h"
 
 namespace ltr {
@@ -81,39 +81,63 @@ __device__ __forceinline__ void store_tile(const Epilogue& e, const f32x16& acc,
 }
 
 // ------------------------------------------------------------------------------------
-// F16 split mode.  K-slab = 32.  LDS tile [128 rows][32 halves] = 64 B rows, 16-byte
-// chunk kc of row r stored at chunk (kc ^ ((r >> 2) & 3)): a ds_read_b128 lane group
-// (16 lanes = rows {0-3,12-15,20-27} ...) then touches 16 distinct 16-B slots of the
-// 256-B bank row -> conflict-free (bank = (addr/4) % 64 for b128).
+// F16 split mode.  K-slab = 32 halves.  Operands go HBM -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write): one wave instruction lands 1 KiB
+// = 16 tile rows x 64 B, LDS destination linear (wave base + lane * 16), so the bank
+// swizzle is applied on the SOURCE side: the lane that fills physical 16-B chunk c of row r
+// fetches logical chunk c ^ ((r >> 2) & 3), and fragment reads apply the same XOR.  With it
+// a ds_read_b128 lane group (rows {0-3,12-15,20-27} / ...) touches 16 distinct 16-B slots of
+// the 256-B bank row -> conflict-free.  Two LDS stages (2 x 24 KiB): slab k+1 streams in
+// while slab k is multiplied; one barrier per slab.  All LDS lives in ONE array (a second
+// __shared__ object makes hipcc drain vmcnt before every ds_read of the pipeline).
+// Epilogue: accumulators -> LDS (per-wave 32x64 f32 strips) -> 16 B per lane coalesced
+// global stores with bias / ReLU / residual / fp16 hi|lo split fused.
 // ------------------------------------------------------------------------------------
 constexpr int BK16 = 32;
+constexpr int PLANE = BM * BK16;                 // halves per operand plane per stage (8 KiB)
+constexpr int STAGE = 3 * PLANE;                 // a_hi | a_lo | w
+constexpr int CLD = 68;                          // f32 row stride of the epilogue strip
 __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
   return row * BK16 + ((kc ^ ((row >> 2) & 3)) << 3);
 }
 
-__global__ void __launch_bounds__(256, 2) gemm_f16s_kernel(
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__global__ void __launch_bounds__(256, 3) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int tiles_m, int tiles_n, Epilogue ep) {
-  __shared__ __attribute__((aligned(16))) __half s_ahi[BM * BK16];
-  __shared__ __attribute__((aligned(16))) __half s_alo[BM * BK16];
-  __shared__ __attribute__((aligned(16))) __half s_w[BN * BK16];
+  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE];   // 48 KiB
 
   int tm, tn;
   tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
-  // staging map: chunk c = tid (+256): row = c >> 2, kc = c & 3
-  const int srow0 = tid >> 2, skc = tid & 3;
-  const int srow1 = srow0 + 64;
-  // clamp out-of-range rows to a valid row: their products land in rows/cols that the
-  // epilogue masks, so no zero fill is needed.
-  const size_t ga0 = (size_t)min(m0 + srow0, M - 1) * K + skc * 8;
-  const size_t ga1 = (size_t)min(m0 + srow1, M - 1) * K + skc * 8;
-  const size_t gw0 = (size_t)min(n0 + srow0, N - 1) * K + skc * 8;
-  const size_t gw1 = (size_t)min(n0 + srow1, N - 1) * K + skc * 8;
-  const int so0 = lds_off_h(srow0, skc), so1 = lds_off_h(srow1, skc);
+  // this lane's two 16-B pieces per plane per slab: tile rows wave*32 + i*16 + (lane >> 2)
+  const __half* ga[2];
+  const __half* gl[2];
+  const __half* gw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 32 + i * 16 + (lane >> 2);
+    const int c_log = (lane & 3) ^ ((row >> 2) & 3);
+    const size_t aoff = (size_t)min(m0 + row, M - 1) * K + c_log * 8;   // rows past M/N: any valid row, masked later
+    ga[i] = a_hi + aoff;
+    gl[i] = a_lo + aoff;
+    gw[i] = w + (size_t)min(n0 + row, N - 1) * K + c_log * 8;
+  }
+  auto issue = [&](int stage, int k0) {
+    __half* base = smem + stage * STAGE + wave * 32 * BK16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ga[i] + k0), (lds_void*)(base + i * 16 * BK16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gl[i] + k0), (lds_void*)(base + PLANE + i * 16 * BK16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gw[i] + k0), (lds_void*)(base + 2 * PLANE + i * 16 * BK16), 16, 0, 0);
+    }
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -123,27 +147,16 @@ __global__ void __launch_bounds__(256, 2) gemm_f16s_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 rh0, rh1, rl0, rl1, rw0, rw1;
-  auto gload = [&](int k0) {
-    rh0 = *reinterpret_cast<const uint4*>(a_hi + ga0 + k0);
-    rh1 = *reinterpret_cast<const uint4*>(a_hi + ga1 + k0);
-    rl0 = *reinterpret_cast<const uint4*>(a_lo + ga0 + k0);
-    rl1 = *reinterpret_cast<const uint4*>(a_lo + ga1 + k0);
-    rw0 = *reinterpret_cast<const uint4*>(w + gw0 + k0);
-    rw1 = *reinterpret_cast<const uint4*>(w + gw1 + k0);
-  };
-  gload(0);
   const int frow = lane & 31, fk = lane >> 5;
-  for (int k0 = 0; k0 < K; k0 += BK16) {
-    __syncthreads();   // previous slab fully consumed
-    *reinterpret_cast<uint4*>(s_ahi + so0) = rh0;
-    *reinterpret_cast<uint4*>(s_ahi + so1) = rh1;
-    *reinterpret_cast<uint4*>(s_alo + so0) = rl0;
-    *reinterpret_cast<uint4*>(s_alo + so1) = rl1;
-    *reinterpret_cast<uint4*>(s_w + so0) = rw0;
-    *reinterpret_cast<uint4*>(s_w + so1) = rw1;
-    __syncthreads();
-    if (k0 + BK16 < K) gload(k0 + BK16);   // prefetch next slab under the MFMAs
+  const int nk = K / BK16;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of slab kt have landed
+    __syncthreads();                                    // everyone's have; slab kt-1 fully consumed
+    if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * BK16);
+    const __half* s_ahi = smem + (kt & 1) * STAGE;
+    const __half* s_alo = s_ahi + PLANE;
+    const __half* s_w = s_ahi + 2 * PLANE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 2 + fk;
@@ -165,11 +178,47 @@ __global__ void __launch_bounds__(256, 2) gemm_f16s_kernel(
         }
     }
   }
+
+  // ---- epilogue through LDS: per-wave strip [32 rows][64 cols] f32, row stride CLD
+  float* s_c = reinterpret_cast<float*>(smem) + wave * 32 * CLD;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int ccol = n0 + wc * 64 + (lane & 15) * 4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ep.bias && ccol < N) bias4 = *reinterpret_cast<const float4*>(ep.bias + ccol);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    __syncthreads();   // K-loop reads (i = 0) / previous strip reads (i = 1) are done
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      store_tile<true>(ep, acc[i][j], m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32 + (lane & 31));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_c[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + j * 32 + lq] = acc[i][j][r];
+    __syncthreads();
+    if (ccol < N) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int srow = it * 4 + (lane >> 4);
+        const int grow = m0 + wr * 64 + i * 32 + srow;
+        if (grow < M) {
+          float4 v = *reinterpret_cast<const float4*>(s_c + srow * CLD + (lane & 15) * 4);
+          v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+          if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          const size_t o = (size_t)grow * N + ccol;
+          if (ep.resid) {
+            const float4 rr = *reinterpret_cast<const float4*>(ep.resid + o);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (ep.out_f32) *reinterpret_cast<float4*>(ep.out_f32 + o) = v;
+          if (ep.out_hi) {
+            __half h[4], l[4];
+            split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]);
+            split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
+            *reinterpret_cast<uint2*>((__half*)ep.out_hi + o) = *reinterpret_cast<const uint2*>(h);
+            *reinterpret_cast<uint2*>((__half*)ep.out_lo + o) = *reinterpret_cast<const uint2*>(l);
+          }
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -255,8 +304,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const float* __restric
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   if (g.M == 0) return LTR_OK;
   const int kmult = wdtype == LTR_W_F16 ? BK16 : BK32;
-  if (g.K % kmult) {
-    set_error("gemm: K=%d must be a multiple of %d", g.K, kmult);
+  if (g.K % kmult || g.N % 64) {
+    set_error("gemm: K=%d must be a multiple of %d and N=%d of 64", g.K, kmult, g.N);
     return LTR_E_INVAL;
   }
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
