@@ -13,8 +13,9 @@
 //    f32 MFMA.
 //  * F32 - exact f32 MFMA (v_mfma_f32_32x32x2_f32) for f32 checkpoints / cross-checks.
 //
-// Tiling (both): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave a
-// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  LDS layouts are chosen per
+// Tiling: each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs); the
+// F16 kernel uses a 128 (M) x 256 (N) tile with 8 waves (activations cost 4 B/elem as hi+lo,
+// weights 2, so the tile is wider in N), the F32 kernel 128x128 with 4 waves.  LDS layouts are chosen per
 // instruction so the fragment reads are conflict-free (see lds_off_* below).  blockIdx is
 // remapped so that consecutive tiles of one XCD share the same weight panel (8 XCDs,
 // private L2s).  The F16 kernel streams operands HBM -> LDS with global_load_lds; the F32
@@ -30,16 +31,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128;
 constexpr int NXCD = 8;
 
-// Workgroup -> tile map.  Hardware places block b on XCD b % 8.  Give each XCD a contiguous
-// run of tiles, walking M fastest inside a run so neighbours reuse the same W panel from
-// that XCD's L2 while the A panel streams.  Bijective for any grid size.
+// Workgroup -> tile map.  Hardware places block b on XCD b % 8 (each XCD has a private
+// 4 MiB L2) and runs ~96 blocks per XCD at a time (32 CUs x 3).  Each XCD gets a contiguous
+// run of the tile list, and the list is in GROUPED order: groups of GM row-tiles, M fastest
+// inside a group, so the ~96 co-resident tiles of an XCD form a GM x (96/GM) patch that
+// shares GM activation panels (4 B/elem: hi+lo) and 96/GM weight panels through that L2,
+// instead of 96 distinct activation panels (measured 13 B/clk/CU of operand fetch was the
+// limiter with the plain M-fastest order).  Bijective for any grid size.
+constexpr int GM = 8;
 __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg / NXCD, r = nwg % NXCD;
   const int xcd = bid % NXCD, k = bid / NXCD;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  tm = lin % tiles_m;
-  tn = lin / tiles_m;
+  const int per_group = GM * tiles_n;
+  const int g = lin / per_group, in_g = lin - g * per_group;
+  const int gm = min(GM, tiles_m - g * GM);          // last group may be short
+  tm = g * GM + in_g % gm;
+  tn = in_g / gm;
 }
 
 struct Epilogue {
@@ -94,9 +103,12 @@ __device__ __forceinline__ void store_tile(const Epilogue& e, const f32x16& acc,
 // global stores with bias / ReLU / residual / fp16 hi|lo split fused.
 // ------------------------------------------------------------------------------------
 constexpr int BK16 = 32;
-constexpr int PLANE = BM * BK16;                 // halves per operand plane per stage (8 KiB)
-constexpr int STAGE = 3 * PLANE;                 // a_hi | a_lo | w
-constexpr int CLD = 68;                          // f32 row stride of the epilogue strip
+constexpr int BN16 = 256;                         // F16 kernel: 128 x 256 tile, 8 waves as 2 (M) x 4 (N)
+constexpr int A_PLANE = BM * BK16;                // halves per activation plane per stage (8 KiB)
+constexpr int W_PLANE = BN16 * BK16;              // 16 KiB
+constexpr int STAGE = 2 * A_PLANE + W_PLANE;      // a_hi | a_lo | w = 32 KiB
+constexpr int CLD = 68;                           // f32 row stride of the epilogue strip
+constexpr int CROWS = 16;                         // rows per epilogue strip
 __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
   return row * BK16 + ((kc ^ ((row >> 2) & 3)) << 3);
 }
@@ -104,39 +116,42 @@ __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-__global__ void __launch_bounds__(256, 3) gemm_f16s_kernel(
+__global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int tiles_m, int tiles_n, Epilogue ep) {
-  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE];   // 48 KiB
+  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE];   // 64 KiB
 
   int tm, tn;
   tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * BN16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave >> 2, wc = wave & 3;
 
-  // this lane's two 16-B pieces per plane per slab: tile rows wave*32 + i*16 + (lane >> 2)
-  const __half* ga[2];
-  const __half* gl[2];
-  const __half* gw[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 32 + i * 16 + (lane >> 2);
+  // global_load_lds pieces of this lane per slab: one 16-row group of each activation plane
+  // (rows wave*16 + (lane>>2)) and two 16-row groups of W (rows wave*32 + i*16 + (lane>>2))
+  const __half *ga, *gl, *gw[2];
+  {
+    const int row = wave * 16 + (lane >> 2);
     const int c_log = (lane & 3) ^ ((row >> 2) & 3);
     const size_t aoff = (size_t)min(m0 + row, M - 1) * K + c_log * 8;   // rows past M/N: any valid row, masked later
-    ga[i] = a_hi + aoff;
-    gl[i] = a_lo + aoff;
-    gw[i] = w + (size_t)min(n0 + row, N - 1) * K + c_log * 8;
-  }
-  auto issue = [&](int stage, int k0) {
-    __half* base = smem + stage * STAGE + wave * 32 * BK16;
+    ga = a_hi + aoff;
+    gl = a_lo + aoff;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_void*)(ga[i] + k0), (lds_void*)(base + i * 16 * BK16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(gl[i] + k0), (lds_void*)(base + PLANE + i * 16 * BK16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(gw[i] + k0), (lds_void*)(base + 2 * PLANE + i * 16 * BK16), 16, 0, 0);
+      const int wrow = wave * 32 + i * 16 + (lane >> 2);
+      const int wc_log = (lane & 3) ^ ((wrow >> 2) & 3);
+      gw[i] = w + (size_t)min(n0 + wrow, N - 1) * K + wc_log * 8;
     }
+  }
+  auto issue = [&](int stage, int k0) {
+    __half* base = smem + stage * STAGE;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(ga + k0), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gl + k0), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gw[i] + k0),
+                                       (lds_void*)(base + 2 * A_PLANE + (wave * 32 + i * 16) * BK16), 16, 0, 0);
   };
 
   f32x16 acc[2][2];
@@ -155,8 +170,8 @@ __global__ void __launch_bounds__(256, 3) gemm_f16s_kernel(
     __syncthreads();                                    // everyone's have; slab kt-1 fully consumed
     if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * BK16);
     const __half* s_ahi = smem + (kt & 1) * STAGE;
-    const __half* s_alo = s_ahi + PLANE;
-    const __half* s_w = s_ahi + 2 * PLANE;
+    const __half* s_alo = s_ahi + A_PLANE;
+    const __half* s_w = s_ahi + 2 * A_PLANE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 2 + fk;
@@ -179,42 +194,51 @@ __global__ void __launch_bounds__(256, 3) gemm_f16s_kernel(
     }
   }
 
-  // ---- epilogue through LDS: per-wave strip [32 rows][64 cols] f32, row stride CLD
-  float* s_c = reinterpret_cast<float*>(smem) + wave * 32 * CLD;
+  // ---- epilogue through LDS: per-wave strip [16 rows][64 cols] f32 (row stride CLD), four
+  // strips per wave (two 32-row MFMA tiles x their two 16-row halves = registers 0-7 / 8-15)
+  float* s_c = reinterpret_cast<float*>(smem) + wave * CROWS * CLD;
   const int lq = lane & 31, lh = lane >> 5;
   const int ccol = n0 + wc * 64 + (lane & 15) * 4;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ep.bias && ccol < N) bias4 = *reinterpret_cast<const float4*>(ep.bias + ccol);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    __syncthreads();   // K-loop reads (i = 0) / previous strip reads (i = 1) are done
+  for (int st = 0; st < 4; ++st) {
+    const int i = st >> 1, half = st & 1;
+    __syncthreads();   // K-loop reads (st = 0) / previous strip reads are done
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_c[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + j * 32 + lq] = acc[i][j][r];
+      for (int r = 0; r < 8; ++r)   // register 8*half + r -> strip row (r & 3) + 8 * (r >> 2) + 4 * lh
+        s_c[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + j * 32 + lq] = acc[i][j][8 * half + r];
     __syncthreads();
     if (ccol < N) {
+      float4 v[4], rr[4];
+      size_t o[4];
+      bool ok[4];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < 4; ++it) {
         const int srow = it * 4 + (lane >> 4);
-        const int grow = m0 + wr * 64 + i * 32 + srow;
-        if (grow < M) {
-          float4 v = *reinterpret_cast<const float4*>(s_c + srow * CLD + (lane & 15) * 4);
-          v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-          if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          const size_t o = (size_t)grow * N + ccol;
-          if (ep.resid) {
-            const float4 rr = *reinterpret_cast<const float4*>(ep.resid + o);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          }
-          if (ep.out_f32) *reinterpret_cast<float4*>(ep.out_f32 + o) = v;
-          if (ep.out_hi) {
-            __half h[4], l[4];
-            split_f16(v.x, h[0], l[0]); split_f16(v.y, h[1], l[1]);
-            split_f16(v.z, h[2], l[2]); split_f16(v.w, h[3], l[3]);
-            *reinterpret_cast<uint2*>((__half*)ep.out_hi + o) = *reinterpret_cast<const uint2*>(h);
-            *reinterpret_cast<uint2*>((__half*)ep.out_lo + o) = *reinterpret_cast<const uint2*>(l);
-          }
+        const int grow = m0 + wr * 64 + i * 32 + half * 16 + srow;
+        ok[it] = grow < M;
+        o[it] = (size_t)grow * N + ccol;
+        v[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + (lane & 15) * 4);
+        rr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep.resid && ok[it]) rr[it] = *reinterpret_cast<const float4*>(ep.resid + o[it]);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (!ok[it]) continue;
+        float4 x = v[it];
+        x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
+        if (ep.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        x.x += rr[it].x; x.y += rr[it].y; x.z += rr[it].z; x.w += rr[it].w;
+        if (ep.out_f32) *reinterpret_cast<float4*>(ep.out_f32 + o[it]) = x;
+        if (ep.out_hi) {
+          __half h[4], l[4];
+          split_f16(x.x, h[0], l[0]); split_f16(x.y, h[1], l[1]);
+          split_f16(x.z, h[2], l[2]); split_f16(x.w, h[3], l[3]);
+          *reinterpret_cast<uint2*>((__half*)ep.out_hi + o[it]) = *reinterpret_cast<const uint2*>(h);
+          *reinterpret_cast<uint2*>((__half*)ep.out_lo + o[it]) = *reinterpret_cast<const uint2*>(l);
         }
       }
     }
@@ -308,11 +332,12 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     set_error("gemm: K=%d must be a multiple of %d and N=%d of 64", g.K, kmult, g.N);
     return LTR_E_INVAL;
   }
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int bn = wdtype == LTR_W_F16 ? BN16 : BN;
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu};
   dim3 grid(tiles_m * tiles_n);
   if (wdtype == LTR_W_F16) {
-    gemm_f16s_kernel<<<grid, 256, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
+    gemm_f16s_kernel<<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
                                           g.N, g.K, tiles_m, tiles_n, ep);
   } else {
     gemm_f32_kernel<<<grid, 256, 0, s>>>((const float*)g.a.hi, (const float*)g.w, g.M, g.N, g.K, tiles_m, tiles_n,
