@@ -128,6 +128,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    from vllm_ltr_amd.distributed import gather_scores
     from vllm_ltr_amd.rank import DeviceQueue, budget_prefix
     from vllm_ltr_amd.scorer import HipOPTScorer
 
@@ -142,7 +143,6 @@ def main():
     ids_d = torch.from_numpy(ids).to(dev)
     cu_d = torch.from_numpy(cu).to(dev)
     shard_scores = torch.empty(n_local, dtype=torch.float32, device=dev)
-    all_scores = torch.empty(n_total, dtype=torch.float32, device=dev)
     queue = DeviceQueue(dev, starv=args.starv, period=args.period, capacity=n_total)
     queue.append(torch.zeros(n_total))
     need_tokens = torch.from_numpy(np.tile(lens, world).astype(np.int32)).to(dev)
@@ -152,8 +152,8 @@ def main():
     def step():
         scorer.score_device(ids_d, cu_d, cu, out=shard_scores)
         if world > 1:
-            dist.all_gather_into_tensor(all_scores, shard_scores)
-            queue._score[:n_total].copy_(all_scores)
+            # the one exchange step of the path: RCCL all-gather of f32 score shards over xGMI
+            queue._score[:n_total].copy_(gather_scores(shard_scores, [n_local] * world))
         else:
             queue._score[:n_total].copy_(shard_scores)
         queue.rank(out=perm)
