@@ -29,7 +29,7 @@ int main() {
   float* d_qkv; __half *d_hi, *d_lo, *d_ohi, *d_olo; float* d_of; int32_t *d_cu, *d_blk;
   (void)hipMalloc(&d_qkv, qkv.size() * 4); (void)hipMalloc(&d_hi, qkv.size() * 2); (void)hipMalloc(&d_lo, qkv.size() * 2);
   (void)hipMalloc(&d_ohi, (size_t)T * H * 2); (void)hipMalloc(&d_olo, (size_t)T * H * 2); (void)hipMalloc(&d_of, (size_t)T * H * 4);
-  (void)hipMalloc(&d_cu, (n + 1) * 4); (void)hipMalloc(&d_blk, (n + 1) * 4);
+  (void)hipMalloc(&d_cu, (n + 1) * 4); (void)hipMalloc(&d_blk, (n + 2) * 4 + (T / 32 + n + 1) * 8);
   (void)hipMemcpy(d_qkv, qkv.data(), qkv.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(d_hi, hi.data(), qkv.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(d_lo, lo.data(), qkv.size() * 2, hipMemcpyHostToDevice);
   (void)hipMemcpy(d_cu, cu.data(), (n + 1) * 4, hipMemcpyHostToDevice);

@@ -10,16 +10,17 @@
 //
 // F16 ("split") mode - attn_f16s_kernel, the production kernel.  q, k, v arrive as fp16
 // hi|lo planes written by the QKV GEMM epilogue.  A workgroup is 4 waves = 128 consecutive
-// queries of one (request, head), 32 per wave; K/V tiles of 32 keys are staged through LDS
-// (next tile prefetched into registers under the MFMAs).  Per 32x32 (key, query) block:
+// queries of one (request, head), 32 per wave; K/V tiles of 32 keys stream HBM -> LDS with
+// global_load_lds (two stages, one barrier per tile).  Per 32x32 (key, query) block:
 //   S^T = K Q^T      on v_mfma_f32_32x32x16_f16, 3 passes (kh*qh + kh*ql + kl*qh)
 //   online softmax   lane-local: with the S^T layout a lane holds 16 keys of ONE query
 //                    (col = lane & 31), so row max / sum are 15 in-lane ops + one
 //                    lane<->lane^32 exchange, and the rescale factor is a per-lane scalar
 //   O^T += V^T P^T   3 passes (vh*ph + vh*pl + vl*ph); the S^T accumulator registers,
 //                    converted to fp16, ARE the B operand (the key <-> k-slot assignment
-//                    of an MFMA is arbitrary as long as A and B agree, so V^T is staged
-//                    in LDS with its keys permuted to match: no cross-lane shuffle).
+//                    of an MFMA is arbitrary as long as A and B agree, so the V^T fragment
+//                    is gathered from the row-major V tile in that key order: no
+//                    cross-lane shuffle and no transposed copy of V).
 // The dropped lo*lo terms are ~2^-22 relative: f32-grade, as in the GEMMs.
 //
 // F32 mode - attn_f32_kernel: exact f32 VALU flash kernel, one query row per lane.
@@ -33,9 +34,13 @@ constexpr int KT = 32;     // keys per LDS tile
 constexpr int D = 64;      // head size (OPT-125m/350m: 768/12 = 1024/16 = 64)
 constexpr float NEG = -1.0e30f;
 
-// blk_start[i] = sum_{j<i} ceil(L_j / qb), i in [0, n_req]
+// Work list of the attention launch: blk_start[i] = sum_{j<i} ceil(L_j / qb) for i in [0, n_req]
+// and, per query block b, blk_desc[b] = (request, first query of the block).  The attention
+// kernels read ONE descriptor instead of binary-searching the prefix table (a chain of ~log2 N
+// dependent loads per workgroup, which dominated the run time for short prompts).
 __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __restrict__ cu, int n_req, int qb,
-                                                           int32_t* __restrict__ blk_start) {
+                                                           int32_t* __restrict__ blk_start,
+                                                           int2* __restrict__ blk_desc) {
   __shared__ int s_w[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -43,7 +48,8 @@ __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __rest
   __syncthreads();
   for (int base = 0; base < n_req; base += 1024) {
     int i = base + tid;
-    int v = (i < n_req) ? (cu[i + 1] - cu[i] + qb - 1) / qb : 0;
+    const int nb = (i < n_req) ? (cu[i + 1] - cu[i] + qb - 1) / qb : 0;
+    int v = nb;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
     if (lane == 63) s_w[wave] = v;
@@ -51,7 +57,10 @@ __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __rest
     int off = carry;
     for (int w = 0; w < wave; ++w) off += s_w[w];
     v += off;
-    if (i < n_req) blk_start[i + 1] = v;
+    if (i < n_req) {
+      blk_start[i + 1] = v;
+      for (int k = 0; k < nb; ++k) blk_desc[v - nb + k] = make_int2(i, k * qb);
+    }
     __syncthreads();
     if (tid == 1023) carry = v;
     __syncthreads();
@@ -60,7 +69,8 @@ __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __rest
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(64) attn_f32_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                      const int32_t* __restrict__ blk_start, int n_req, int H,
+                                                      const int32_t* __restrict__ blk_start,
+                                                      const int2* __restrict__ blk_desc, int n_req, int H,
                                                       float scale_log2e, void* out_hi, void* out_lo) {
   __shared__ __attribute__((aligned(16))) float s_k[KT * D];
   __shared__ __attribute__((aligned(16))) float s_v[KT * D];
@@ -68,8 +78,9 @@ __global__ void __launch_bounds__(64) attn_f32_kernel(const float* __restrict__ 
   if (b >= blk_start[n_req]) return;
   const int head = blockIdx.y;
   const int lane = threadIdx.x;
-  const int r = find_request(blk_start, n_req, b);
-  const int q0 = (b - blk_start[r]) * QB;
+  const int2 desc = blk_desc[b];
+  const int r = desc.x;
+  const int q0 = desc.y;
   const int t0 = cu[r] - cu[0];
   const int L = cu[r + 1] - cu[r];
   const int qi = q0 + lane;
@@ -171,31 +182,38 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TK = 32;   // keys per tile = one 32x32 MFMA block
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
-// K tile [32 keys][64 d] halves, 128-B rows of 8 16-B chunks; chunk c of row r lives at
-// c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots.
+// LDS stage: K hi | K lo | V hi | V lo, each [32 keys][64 d] halves (4 KiB), filled by
+// global_load_lds (lane-linear image: one wave instruction = 8 rows x 128 B).
+// K: 16-B chunk c of row r holds logical chunk c ^ ((r >> 1) & 7) (source-side swizzle) so
+// the ds_read_b128 A-fragment reads are conflict-free.  V: plain row-major; its fragments
+// (8 keys of one d column per lane) are gathered with 2-byte reads - lanes of a half-wave
+// read 32 consecutive halves of one key row, which is conflict-free - so no transposed
+// copy of V is ever written.
+constexpr int PLANE_H = TK * D;                 // halves per plane
+constexpr int ATT_STAGE = 4 * PLANE_H;          // 16 KiB
+constexpr int NSTAGE = 3;
 __device__ __forceinline__ int k_off(int row, int c) { return row * D + ((c ^ ((row >> 1) & 7)) << 3); }
-// V^T tile [64 d][32 key slots] halves, 64-B rows of 4 chunks; chunk c of row r at c ^ ((r >> 2) & 3).
-__device__ __forceinline__ int v_off(int row, int c) { return row * TK + ((c ^ ((row >> 2) & 3)) << 3); }
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
-    const int32_t* __restrict__ blk_start, int n_req, int H, float scale_log2e, __half* __restrict__ out_hi,
-    __half* __restrict__ out_lo) {
-  __shared__ __attribute__((aligned(16))) __half s_k[2][TK * D];    // hi, lo
-  __shared__ __attribute__((aligned(16))) __half s_v[2][D * TK];    // hi, lo (transposed, keys permuted)
+    const int32_t* __restrict__ blk_start, const int2* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
+    __half* __restrict__ out_hi, __half* __restrict__ out_lo) {
+  __shared__ __attribute__((aligned(16))) __half smem[NSTAGE * ATT_STAGE];   // 48 KiB ring, tiles it+1 and it+2 in flight
   constexpr int QBLK = 32 * NW;
-  constexpr int NT = NW * 64;
-  constexpr int ITERS = (TK * 8) / NT;   // 16-B chunks per plane per thread
+  static_assert(NW == 4, "load map below assumes 4 waves (one 8-row group of each plane per wave)");
 
   const int b = blockIdx.x;
   if (b >= blk_start[n_req]) return;
   const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = find_request(blk_start, n_req, b);
-  const int qblk0 = (b - blk_start[r]) * QBLK;
+  const int2 desc = blk_desc[b];
+  const int r = desc.x;
+  const int qblk0 = desc.y;
   const int t0 = cu[r] - cu[0];
   const int L = cu[r + 1] - cu[r];
   const int q0 = qblk0 + wave * 32;
@@ -218,50 +236,37 @@ __global__ void __launch_bounds__(NW * 64) attn_f16s_kernel(
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = NEG, l = 0.f;
 
-  const int kend = min(L, qblk0 + QBLK);      // keys needed by this block: [0, kend)
-  uint4 pk[ITERS][4];                          // prefetch: k_hi, k_lo, v_hi, v_lo chunks
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int c = it * NT + tid;
-      const int key = c >> 3, dc = c & 7;
-      const size_t base = (size_t)(t0 + min(kt + key, L - 1)) * ld + head * D + dc * 8;
-      pk[it][0] = *reinterpret_cast<const uint4*>(qkv_hi + base + H);
-      pk[it][1] = *reinterpret_cast<const uint4*>(qkv_lo + base + H);
-      pk[it][2] = *reinterpret_cast<const uint4*>(qkv_hi + base + 2 * H);
-      pk[it][3] = *reinterpret_cast<const uint4*>(qkv_lo + base + 2 * H);
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int c = it * NT + tid;
-      const int key = c >> 3, dc = c & 7;
-      *reinterpret_cast<uint4*>(&s_k[0][k_off(key, dc)]) = pk[it][0];
-      *reinterpret_cast<uint4*>(&s_k[1][k_off(key, dc)]) = pk[it][1];
-      // key -> (chunk, element) of the V^T row so that it matches the S^T register order:
-      // register e of k-step g on lane-half h holds key 16g + 8(e>>2) + 4h + (e&3)
-      const int g = key >> 4, k16 = key & 15;
-      const int h = (k16 >> 2) & 1, e = (k16 & 3) + 4 * (k16 >> 3);
-      const int chunk = g * 2 + h;
-      const __half* vh = reinterpret_cast<const __half*>(&pk[it][2]);
-      const __half* vl = reinterpret_cast<const __half*>(&pk[it][3]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = dc * 8 + i;
-        s_v[0][v_off(row, chunk) + e] = vh[i];
-        s_v[1][v_off(row, chunk) + e] = vl[i];
-      }
-    }
+  // tile loads: wave w fills rows 8w..8w+7 of each of the four planes (1 KiB each)
+  const int lrow = wave * 8 + (lane >> 3);                      // key row inside the tile
+  const int kc_log = (lane & 7) ^ ((lrow >> 1) & 7);            // K: swizzled source chunk
+  const int vc = lane & 7;                                      // V: linear
+  auto issue = [&](int stage, int kt) {
+    const size_t rowoff = (size_t)(t0 + min(kt + lrow, L - 1)) * ld + head * D;
+    __half* base = smem + stage * ATT_STAGE + wave * 8 * D;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc_log * 8), (lds_void*)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + vc * 8), (lds_void*)(base + 2 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
   };
 
-  gload(0);
-  for (int kt = 0; kt < kend; kt += TK) {
-    __syncthreads();
-    sstore();
-    __syncthreads();
-    if (kt + TK < kend) gload(kt + TK);
-    if (!wave_active || kt > q0) continue;       // wave-uniform: past this wave's diagonal
+  const int kend = min(L, qblk0 + QBLK);      // keys needed by this block: [0, kend)
+  const int ntile = (kend + TK - 1) / TK;
+  // Ring of three stages: when tile `it` is multiplied, tiles it+1 and it+2 are in flight
+  // (prompts are short, so a wave's per-tile math is shorter than the HBM round trip; one
+  // tile of look-ahead left the waves parked on vmcnt).  Counted waits: 4 loads per tile.
+  issue(0, 0);
+  if (ntile > 1) issue(1, TK);
+  for (int it = 0; it < ntile; ++it) {
+    const int kt = it * TK;
+    if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it landed, it+1 may fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // everyone's rows landed; tile it-1 fully consumed
+    if (it + 2 < ntile) issue((it + 2) % NSTAGE, kt + 2 * TK);
+    if (!wave_active || kt > q0) continue;              // wave-uniform: past this wave's diagonal
+    const __half* s_khi = smem + (it % NSTAGE) * ATT_STAGE;
+    const __half* s_klo = s_khi + PLANE_H;
+    const __half* s_vhi = s_khi + 2 * PLANE_H;
+    const __half* s_vlo = s_khi + 3 * PLANE_H;
 
     // ---- S^T = K Q^T (rows = keys, cols = queries)
     f32x16 sacc;
@@ -270,8 +275,8 @@ __global__ void __launch_bounds__(NW * 64) attn_f16s_kernel(
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = 2 * ks + lh;
-      const f16x8 kh = *reinterpret_cast<const f16x8*>(&s_k[0][k_off(lq, c)]);
-      const f16x8 kl = *reinterpret_cast<const f16x8*>(&s_k[1][k_off(lq, c)]);
+      const f16x8 kh = *reinterpret_cast<const f16x8*>(s_khi + k_off(lq, c));
+      const f16x8 kl = *reinterpret_cast<const f16x8*>(s_klo + k_off(lq, c));
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc, 0, 0, 0);
@@ -289,32 +294,41 @@ __global__ void __launch_bounds__(NW * 64) attn_f16s_kernel(
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // raw v_exp_f32: arguments <= 0, underflow to 0 is wanted
     m = m_new;
     float psum = 0.f;
-    f16x8 ph[2], pl[2];
+    f16x8 ph0, ph1, pl0, pl1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float p = exp2f(sacc[i] - m_new);
-      psum += p;
-      const _Float16 hi = (_Float16)p;
-      ph[i >> 3][i & 7] = hi;
-      pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
+    for (int i = 0; i < 8; ++i) {
+      const float p0 = __builtin_amdgcn_exp2f(sacc[i] - m_new), p1 = __builtin_amdgcn_exp2f(sacc[8 + i] - m_new);
+      psum += p0 + p1;
+      const _Float16 h0 = (_Float16)p0, h1 = (_Float16)p1;
+      ph0[i] = h0; ph1[i] = h1;
+      pl0[i] = (_Float16)(p0 - (float)h0);
+      pl1[i] = (_Float16)(p1 - (float)h1);
     }
     l = l * alpha + psum;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    // ---- O^T += V^T P^T  (rows = d, cols = queries)
+    // ---- O^T += V^T P^T  (rows = d, cols = queries).  A fragment of k-step g: element e of
+    // lane-half lh is key 16g + 8(e>>2) + 4lh + (e&3) - the accumulator register order of S^T -
+    // gathered from the row-major V tile with 2-byte reads.
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int row = dt * 32 + lq, c = g * 2 + lh;
-        const f16x8 vh = *reinterpret_cast<const f16x8*>(&s_v[0][v_off(row, c)]);
-        const f16x8 vl = *reinterpret_cast<const f16x8*>(&s_v[1][v_off(row, c)]);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], o[dt], 0, 0, 0);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], o[dt], 0, 0, 0);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[g], o[dt], 0, 0, 0);
+        f16x8 vh, vl;
+        const int vbase = (16 * g + 4 * lh) * D + dt * 32 + lq;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int off = vbase + (8 * (e >> 2) + (e & 3)) * D;
+          vh[e] = reinterpret_cast<const _Float16*>(s_vhi)[off];
+          vl[e] = reinterpret_cast<const _Float16*>(s_vlo)[off];
+        }
+        const f16x8 ph = g ? ph1 : ph0, pl = g ? pl1 : pl0;
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
       }
     }
   }
@@ -345,23 +359,25 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
   if (n_req == 0 || T == 0) return LTR_OK;
   if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
   const float scale_log2e = 0.125f * 1.4426950408889634f;   // d^-0.5 (opt.py:73) * log2(e)
+  // scratch layout: int32 blk_start[n_req + 1] (padded to 8 B) | int2 blk_desc[max blocks]
+  int2* blk_desc = reinterpret_cast<int2*>(blk_start + ((n_req + 1 + 1) & ~1));
   if (wdtype == LTR_W_F16) {
     constexpr int NW = 4;
-    attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start);
+    attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start, blk_desc);
     LTR_LAUNCH_CHECK();
     dim3 grid(T / (32 * NW) + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
-    attn_f16s_kernel<NW><<<grid, NW * 64, 0, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, n_req,
-                                                  H, scale_log2e, (__half*)out.hi, (__half*)out.lo);
+    attn_f16s_kernel<NW><<<grid, NW * 64, 0, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
+                                                  n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo);
   } else {
-    attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start);
+    attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start, blk_desc);
     LTR_LAUNCH_CHECK();
     dim3 grid(T / QB + n_req, n_heads);
     if (wdtype == LTR_W_F32)
-      attn_f32_kernel<false><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, n_req, H, scale_log2e, out.hi,
-                                                 out.lo);
+      attn_f32_kernel<false><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, blk_desc, n_req, H, scale_log2e,
+                                                 out.hi, out.lo);
     else   // debug A/B (wdtype -1): f32 VALU attention feeding split operands
-      attn_f32_kernel<true><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, n_req, H, scale_log2e, out.hi,
-                                                out.lo);
+      attn_f32_kernel<true><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, blk_desc, n_req, H, scale_log2e,
+                                                out.hi, out.lo);
   }
   LTR_LAUNCH_CHECK();
   return LTR_OK;
