@@ -117,7 +117,8 @@ struct ProfScope {
 
 // one request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch
 int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev, int N_total, int r0, int r1, int t0,
-                  int t1, int n_layers, const Workspace& ws, double sum_l2, hipStream_t s) {
+                  int t1, int n_layers, const Workspace& ws, double sum_l2, bool prune_last, const float** h_final,
+                  hipStream_t s) {
   const ltr_model_desc& d = m->d;
   const int wd = d.weight_dtype;
   const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim;
@@ -125,14 +126,18 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   int rc;
   // --- embedding (opt.py:241-245)
   const double wbytes = wd == LTR_W_F16 ? 2.0 : 4.0;
-  const double ln_bytes = (double)Tc * H * 8.0;   // read f32 row + write operand row (4 B/elem)
+  // rows / buffers of the part of a layer after attention: all Tc token rows, except in the
+  // last layer of a scoring call where only the nreq last-token rows are carried on (below)
+  int Mr = Tc;
+  float* hb = ws.h;
+  AOp ab = ws.a, fb = ws.f;
   auto gemm = [&](const GemmArgs& g) {
     ProfScope p(m, LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
     return launch_gemm(wd, g, s);
   };
-  auto lnorm = [&](const float* x, const float* gw_, const float* gb_, float* of, AOp oo) {
-    ProfScope p(m, LTR_K_LN, ln_bytes + (of ? (double)Tc * H * 4.0 : 0.0), s);
-    return launch_layernorm(wd, x, gw_, gb_, Tc, H, of, oo, s);
+  auto lnorm = [&](int rows, const float* x, const float* gw_, const float* gb_, float* of, AOp oo) {
+    ProfScope p(m, LTR_K_LN, (double)rows * H * (of ? 12.0 : 8.0), s);   // f32 row in, operand row (+f32 row) out
+    return launch_layernorm(wd, x, gw_, gb_, rows, H, of, oo, s);
   };
   {
     ProfScope p(m, LTR_K_EMBED, (double)Tc * (8.0 + (De + H) * wbytes + H * 4.0), s);
@@ -153,7 +158,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   for (int L = 0; L < nl; ++L) {
     // --- attention half (opt.py:152-163)
     if (d.pre_ln) {
-      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ws.a);
+      rc = lnorm(Tc, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ws.a);
       if (rc) return rc;
     }
     {
@@ -169,38 +174,54 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
                             ws.blk, ws.a, s);
     }
     if (rc) return rc;
+    if (prune_last && L == nl - 1) {
+      // Only the last token of each prompt is scored (logits_processor.py:74-79), and after the
+      // attention of the LAST layer no token reads another token's state: out_proj, the LayerNorms
+      // and the MLP are per-token maps.  Compact the nreq last-token rows of h and of the attention
+      // output and run the rest of the layer on those rows only (bit-identical per row; saves
+      // ~3/4 of the last layer's GEMM work).  Buffers: the qkv region (dead after attention) holds
+      // the compact h and operand, the f region the compact MLP intermediate.
+      char* q = (char*)ws.qkv.hi;
+      hb = (float*)q;
+      char* a2 = q + (((size_t)nreq * H * 4 + 255) & ~(size_t)255);
+      ab = wd == LTR_W_F16 ? AOp{a2, a2 + (size_t)nreq * H * 2} : AOp{a2, nullptr};
+      fb = wd == LTR_W_F16 ? AOp{ws.f.hi, (char*)ws.f.hi + (size_t)nreq * F * 2} : ws.f;
+      Mr = nreq;
+      if ((rc = launch_gather_last_rows(wd, cu_dev + r0, t0, nreq, H, ws.h, ws.a, hb, ab, s))) return rc;
+    }
     {
       GemmArgs g{};
-      g.a = ws.a; g.w = m->lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
-      g.resid = ws.h; g.out_f32 = ws.h; g.M = Tc; g.N = H; g.K = H;
+      g.a = ab; g.w = m->lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
+      g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {   // 350m: LN after the residual add; h and its operand copy
-      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), ws.h, ws.a);
+      rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), hb, ab);
       if (rc) return rc;
     }
     // --- feed-forward half (opt.py:165-175)
     if (d.pre_ln) {
-      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), nullptr, ws.a);
+      rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), nullptr, ab);
       if (rc) return rc;
     }
     {
       GemmArgs g{};
-      g.a = ws.a; g.w = m->lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
-      g.out_split = ws.f; g.relu = 1; g.M = Tc; g.N = F; g.K = H;
+      g.a = ab; g.w = m->lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
+      g.out_split = fb; g.relu = 1; g.M = Mr; g.N = F; g.K = H;
       if ((rc = gemm(g))) return rc;
     }
     {
       GemmArgs g{};
-      g.a = ws.f; g.w = m->lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
-      g.resid = ws.h; g.out_f32 = ws.h; g.M = Tc; g.N = H; g.K = F;
+      g.a = fb; g.w = m->lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
+      g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F;
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {
-      rc = lnorm(ws.h, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), ws.h, ws.a);
+      rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), hb, ab);
       if (rc) return rc;
     }
   }
+  *h_final = hb;   // ws.h, or the compact last-token rows when the last layer was pruned
   return LTR_OK;
 }
 
@@ -334,13 +355,16 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
     double sum_l2 = 0.0;
     for (int r = r0; r < r1; ++r) { const double L = cu[r + 1] - cu[r]; sum_l2 += L * L; }
-    rc = forward_chunk(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, sum_l2, s);
+    const bool prune = !hidden_out && d.num_layers > 0;
+    const float* h_final = ws.h;
+    rc = forward_chunk(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, sum_l2, prune, &h_final, s);
     if (rc) return rc;
     if (hidden_out) {
       LTR_HIP_CHECK(hipMemcpyAsync(hidden_out, ws.h, (size_t)(t1 - t0) * d.hidden_size * 4, hipMemcpyDeviceToDevice, s));
     } else {
       ProfScope p(h, LTR_K_POOL, (double)(r1 - r0) * (d.hidden_size * 4.0 + 4.0), s);
-      rc = launch_pool_head(d.weight_dtype, ws.h, cu_seqlens + r0, t0, r1 - r0, d.hidden_size, d.word_embed_proj_dim,
+      rc = launch_pool_head(d.weight_dtype, h_final, prune ? nullptr : cu_seqlens + r0, t0, r1 - r0, d.hidden_size,
+                            d.word_embed_proj_dim,
                             d.num_labels, (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
                             d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
                             h->gw(LTR_WT_SCORE), scores_out + r0, logits_out ? logits_out + (size_t)r0 * d.num_labels : nullptr, s);

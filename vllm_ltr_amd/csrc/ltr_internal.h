@@ -63,6 +63,9 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
 int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
                      float* out_f32 /*nullable, may alias x*/, AOp out_op /*nullable*/, hipStream_t s);
 int launch_to_operand(int wdtype, const float* x, int64_t n, AOp out, hipStream_t s);
+// compact the last-token rows (cu[i+1]-1-tok_off) of the f32 stream and of an operand buffer to [n_req, H]
+int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_req, int H, const float* h_src, AOp a_src,
+                            float* h_dst, AOp a_dst, hipStream_t s);
 
 int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N, int T, int tok_off,
                         const void* tok_table, int De, int vocab, const void* pos_table, int H, int pos_rows,
@@ -74,7 +77,8 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]
                      int T, int H, int n_heads, int32_t* blk_start /*scratch: (n_req+2)*4 + (T/32+n_req+1)*8 bytes*/, AOp out,
                      hipStream_t s);
 
-int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu, int tok_off, int N, int H, int De,
+int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu /*nullptr: rows are already compact*/, int tok_off,
+                     int N, int H, int De,
                      int num_labels, const float* ln_w, const float* ln_b, const void* proj_out,
                      const void* score_w, float* scores_out, float* logits_out, hipStream_t s);
 

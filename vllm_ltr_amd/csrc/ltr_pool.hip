@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(PH_THREADS) pool_head_kernel(
   __shared__ int s_besti;
   const int req = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t row = (size_t)(cu[req + 1] - 1 - tok_off);
+  const size_t row = cu ? (size_t)(cu[req + 1] - 1 - tok_off) : (size_t)req;   // cu == nullptr: compact rows
   const float* xr = hidden + row * H;
   float part = 0.f;
   for (int c = tid; c < H; c += PH_THREADS) { float v = xr[c]; s_x[c] = v; part += v; }

@@ -142,6 +142,33 @@ __global__ void __launch_bounds__(256) layernorm_kernel(
   }
 }
 
+// Last-token rows of the residual stream (f32) and of an operand buffer, compacted to [n_req, H]:
+// the decoder's last layer only needs them after attention (see forward_chunk).
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) gather_last_rows_kernel(const int32_t* __restrict__ cu, int tok_off, int n_req,
+                                                               int H, int64_t plane_src, int64_t plane_dst,
+                                                               const float* __restrict__ h_src, const char* a_src,
+                                                               float* __restrict__ h_dst, char* a_dst) {
+  const int lane = threadIdx.x & 63;
+  const int req = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (req >= n_req) return;
+  const size_t srow = (size_t)(cu[req + 1] - 1 - tok_off), drow = (size_t)req;
+  for (int c = lane * 8; c < H; c += 512) {
+    float v[8];
+    Vec8<float>::load(h_src + srow * H + c, v);
+    store8_f32(h_dst + drow * H + c, v);
+    if (SPLIT) {   // fp16 hi | lo planes: 16 B per plane
+      const __half* sh = reinterpret_cast<const __half*>(a_src);
+      __half* dh = reinterpret_cast<__half*>(a_dst);
+      *reinterpret_cast<uint4*>(dh + drow * H + c) = *reinterpret_cast<const uint4*>(sh + srow * H + c);
+      *reinterpret_cast<uint4*>(dh + plane_dst + drow * H + c) = *reinterpret_cast<const uint4*>(sh + plane_src + srow * H + c);
+    } else {
+      Vec8<float>::load(reinterpret_cast<const float*>(a_src) + srow * H + c, v);
+      store8_f32(reinterpret_cast<float*>(a_dst) + drow * H + c, v);
+    }
+  }
+}
+
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) to_operand_kernel(const float* __restrict__ x, int64_t n8, void* hi,
                                                          void* lo) {
@@ -187,6 +214,22 @@ int launch_layernorm(int wdtype, const float* x, const float* gamma, const float
     if (maxv <= 1) LN_LAUNCH(false, 1); else if (maxv == 2) LN_LAUNCH(false, 2); else LN_LAUNCH(false, 4);
   }
 #undef LN_LAUNCH
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_req, int H, const float* h_src, AOp a_src,
+                            float* h_dst, AOp a_dst, hipStream_t s) {
+  if (n_req == 0) return LTR_OK;
+  dim3 grid((n_req + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  if (wdtype == LTR_W_F16) {
+    const int64_t ps = ((const __half*)a_src.lo - (const __half*)a_src.hi), pd = ((__half*)a_dst.lo - (__half*)a_dst.hi);
+    gather_last_rows_kernel<true><<<grid, 256, 0, s>>>(cu, tok_off, n_req, H, ps, pd, h_src, (const char*)a_src.hi, h_dst,
+                                                       (char*)a_dst.hi);
+  } else {
+    gather_last_rows_kernel<false><<<grid, 256, 0, s>>>(cu, tok_off, n_req, H, 0, 0, h_src, (const char*)a_src.hi, h_dst,
+                                                        (char*)a_dst.hi);
+  }
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
