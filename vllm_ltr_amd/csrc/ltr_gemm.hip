@@ -116,11 +116,18 @@ __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+#ifdef LTR_GEMM_TIMELINE
+__device__ unsigned long long g_timeline[8192 * 4];
+#endif
+
 __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int tiles_m, int tiles_n, Epilogue ep) {
   __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE];   // 64 KiB
 
+#ifdef LTR_GEMM_TIMELINE
+  const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
   int tm, tn;
   tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN16;
@@ -194,55 +201,92 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     }
   }
 
+#ifdef LTR_GEMM_TIMELINE
+  const unsigned long long tl1 = __builtin_readcyclecounter();
+#endif
   // ---- epilogue through LDS: per-wave strip [16 rows][64 cols] f32 (row stride CLD), four
-  // strips per wave (two 32-row MFMA tiles x their two 16-row halves = registers 0-7 / 8-15)
+  // strips per wave (two 32-row MFMA tiles x their two 16-row halves = registers 0-7 / 8-15).
+  // Each wave touches only its own strip, so after ONE workgroup barrier (the K-loop's LDS reads
+  // are done) the strips are wave-local: LDS executes a wave's instructions in order, an
+  // s_waitcnt between the writes and the transposed reads is all the synchronisation needed.
+  // Read-back: a lane owns 8 consecutive columns -> 16-B stores for f32 and for each fp16 plane.
   float* s_c = reinterpret_cast<float*>(smem) + wave * CROWS * CLD;
   const int lq = lane & 31, lh = lane >> 5;
-  const int ccol = n0 + wc * 64 + (lane & 15) * 4;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (ep.bias && ccol < N) bias4 = *reinterpret_cast<const float4*>(ep.bias + ccol);
+  const int erow = lane >> 3, ecol = (lane & 7) * 8;
+  const int ccol = n0 + wc * 64 + ecol;
+  float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
+  if (ep.bias && ccol < N) {
+    bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
+    bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol + 4);
+  }
+  __syncthreads();
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     const int i = st >> 1, half = st & 1;
-    __syncthreads();   // K-loop reads (st = 0) / previous strip reads are done
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 8; ++r)   // register 8*half + r -> strip row (r & 3) + 8 * (r >> 2) + 4 * lh
         s_c[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + j * 32 + lq] = acc[i][j][8 * half + r];
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     if (ccol < N) {
-      float4 v[4], rr[4];
-      size_t o[4];
-      bool ok[4];
+      float4 va[2], vb[2], ra[2], rb[2];
+      size_t o[2];
+      bool ok[2];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int srow = it * 4 + (lane >> 4);
+      for (int it = 0; it < 2; ++it) {
+        const int srow = it * 8 + erow;
         const int grow = m0 + wr * 64 + i * 32 + half * 16 + srow;
         ok[it] = grow < M;
         o[it] = (size_t)grow * N + ccol;
-        v[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + (lane & 15) * 4);
-        rr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ep.resid && ok[it]) rr[it] = *reinterpret_cast<const float4*>(ep.resid + o[it]);
+        va[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
+        vb[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol + 4);
+        ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[it] = ra[it];
+        if (ep.resid && ok[it]) {
+          ra[it] = *reinterpret_cast<const float4*>(ep.resid + o[it]);
+          rb[it] = *reinterpret_cast<const float4*>(ep.resid + o[it] + 4);
+        }
       }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 2; ++it) {
         if (!ok[it]) continue;
-        float4 x = v[it];
-        x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
-        if (ep.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-        x.x += rr[it].x; x.y += rr[it].y; x.z += rr[it].z; x.w += rr[it].w;
-        if (ep.out_f32) *reinterpret_cast<float4*>(ep.out_f32 + o[it]) = x;
+        float x[8] = {va[it].x + bias_a.x, va[it].y + bias_a.y, va[it].z + bias_a.z, va[it].w + bias_a.w,
+                      vb[it].x + bias_b.x, vb[it].y + bias_b.y, vb[it].z + bias_b.z, vb[it].w + bias_b.w};
+        if (ep.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        x[0] += ra[it].x; x[1] += ra[it].y; x[2] += ra[it].z; x[3] += ra[it].w;
+        x[4] += rb[it].x; x[5] += rb[it].y; x[6] += rb[it].z; x[7] += rb[it].w;
+        if (ep.out_f32) {
+          *reinterpret_cast<float4*>(ep.out_f32 + o[it]) = make_float4(x[0], x[1], x[2], x[3]);
+          *reinterpret_cast<float4*>(ep.out_f32 + o[it] + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        }
         if (ep.out_hi) {
-          __half h[4], l[4];
-          split_f16(x.x, h[0], l[0]); split_f16(x.y, h[1], l[1]);
-          split_f16(x.z, h[2], l[2]); split_f16(x.w, h[3], l[3]);
-          *reinterpret_cast<uint2*>((__half*)ep.out_hi + o[it]) = *reinterpret_cast<const uint2*>(h);
-          *reinterpret_cast<uint2*>((__half*)ep.out_lo + o[it]) = *reinterpret_cast<const uint2*>(l);
+          __half h[8], l[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
+          *reinterpret_cast<uint4*>((__half*)ep.out_hi + o[it]) = *reinterpret_cast<const uint4*>(h);
+          *reinterpret_cast<uint4*>((__half*)ep.out_lo + o[it]) = *reinterpret_cast<const uint4*>(l);
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
+#ifdef LTR_GEMM_TIMELINE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_timeline[blockIdx.x * 4 + 0] = tl0;
+    g_timeline[blockIdx.x * 4 + 1] = tl1;
+    g_timeline[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
+    g_timeline[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -324,6 +368,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const float* __restric
 }
 
 }  // namespace
+
+#ifdef LTR_GEMM_TIMELINE
+int gemm_timeline_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8192 * 4); }
+#endif
 
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   if (g.M == 0) return LTR_OK;
