@@ -119,6 +119,22 @@ def test_pool_head_kernel_alone(dev, mk, mode):
         assert (scores.cpu().numpy() == want.argmax(-1)).all()
 
 
+@pytest.mark.parametrize("mk", [OPTSpec.tiny_pre_ln, OPTSpec.tiny_post_ln])
+def test_last_layer_pruning_is_invisible(dev, mk):
+    """ltr_score carries only the last-token rows through the tail of the last layer;
+    ltr_forward_hidden runs every row.  Pooling the full hidden states must give the same
+    scores bit for bit (out_proj / LayerNorm / MLP are per-token maps)."""
+    spec = mk()
+    ckpt = seeded_checkpoint(spec, 6)
+    ids, cu = synthetic_batch(spec, [9, 1, 64, 65, 2, 130, 33, 128, 31], 10)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    pruned = sc.score(ids, cu)
+    h = torch.from_numpy(sc.hidden(ids, cu, n_layers=-1)).to(dev)
+    full = torch.empty(len(cu) - 1, device=dev)
+    sc.pool_head_device(h, torch.from_numpy(cu).to(dev), len(cu) - 1, full)
+    assert np.array_equal(pruned, full.cpu().numpy())
+
+
 def test_chunking_is_invisible(dev):
     """Scores do not depend on how the batch is cut into passes."""
     spec = OPTSpec.tiny_pre_ln()

@@ -198,7 +198,7 @@ constexpr int NSTAGE = 3;
 __device__ __forceinline__ int k_off(int row, int c) { return row * D + ((c ^ ((row >> 1) & 7)) << 3); }
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) attn_f16s_kernel(
+__global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
     const int32_t* __restrict__ blk_start, const int2* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
     __half* __restrict__ out_hi, __half* __restrict__ out_lo) {
@@ -281,35 +281,41 @@ __global__ void __launch_bounds__(NW * 64) attn_f16s_kernel(
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc, 0, 0, 0);
     }
-    // ---- online softmax for query lq (this lane: 16 of its 32 keys; lane^32: the others)
-    const bool diag = kt == q0;
-    float mx = NEG;
+    // ---- online softmax for query lq (this lane: 16 of its 32 keys; lane^32: the others).
+    // Scores stay raw in the accumulator; p = exp2(s * c - m) is one fma + one v_exp_f32.
+    // The running reference m is only raised when some query of the wave sees a score more
+    // than 8 (log2 units) above it, so in most tiles the O accumulators are not touched by the
+    // VALU at all (p <= 2^8 is exact work for the fp16 hi|lo split and the f32 row sum).
+    if (kt == q0) {                                             // diagonal tile: causal mask
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = sacc[i] * scale_log2e;
-      const int key = (i & 3) + 8 * (i >> 2) + 4 * lh;      // relative to kt
-      if (diag && key > lq) v = NEG;                          // causal
-      sacc[i] = v;
-      mx = fmaxf(mx, v);
+      for (int i = 0; i < 16; ++i)
+        if ((i & 3) + 8 * (i >> 2) + 4 * lh > lq) sacc[i] = NEG;   // key (relative to kt) > query
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // raw v_exp_f32: arguments <= 0, underflow to 0 is wanted
-    m = m_new;
+    float mx = sacc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;      // scale > 0 commutes with max
+    if (__any(mx > m + 8.0f)) {                                  // wave-uniform
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);     // raw v_exp_f32: argument <= 0, underflow to 0 is wanted
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    }
     float psum = 0.f;
     f16x8 ph0, ph1, pl0, pl1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float p0 = __builtin_amdgcn_exp2f(sacc[i] - m_new), p1 = __builtin_amdgcn_exp2f(sacc[8 + i] - m_new);
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale_log2e, -m));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[8 + i], scale_log2e, -m));
       psum += p0 + p1;
       const _Float16 h0 = (_Float16)p0, h1 = (_Float16)p1;
       ph0[i] = h0; ph1[i] = h1;
       pl0[i] = (_Float16)(p0 - (float)h0);
       pl1[i] = (_Float16)(p1 - (float)h1);
     }
-    l = l * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    l += psum;
     // ---- O^T += V^T P^T  (rows = d, cols = queries).  A fragment of k-step g: element e of
     // lane-half lh is key 16g + 8(e>>2) + 4lh + (e&3) - the accumulator register order of S^T -
     // gathered from the row-major V tile with 2-byte reads.
