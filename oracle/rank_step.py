@@ -33,7 +33,6 @@ import numpy as np
 class Req:
     """The fields of ``SequenceGroup`` the ranking touches
     (sequence.py:426-433, scheduler.py:372-374)."""
-    __slots__ = ("request_id", "aux_model_score", "pri", "idle", "runs")
 
     def __init__(self, request_id: str, score: Optional[float] = None):
         self.request_id = request_id
@@ -85,6 +84,27 @@ def rtpt_order(reqs: Sequence[Req]) -> List[Req]:     # scheduler.py:961
 
 def ropt_order(reqs: Sequence[Req]) -> List[Req]:     # scheduler.py:1015
     return list(sorted(reqs, key=lambda req: req.aux_model_score))
+
+
+def xpt_expected_length(aux_model_score: float, key: Sequence[float], value: Sequence[float]) -> float:
+    """scheduler.py:920-931: expected output length looked up from the score->length table
+    (``self.distribution = (key, value)``, loaded at :312)."""
+    score = round(-aux_model_score, 2)
+    expected_length = -10000
+    for kid in range(len(key) - 1, -1, -1):
+        if score >= key[kid]:
+            expected_length = value[kid]
+            break
+    return expected_length
+
+
+def xpt_order(reqs, key, value, output_len) -> list:
+    """scheduler.py:910-933 (``_get_xpt_ordered_requests``): SRTF on the table's expected length;
+    ``output_len(req)`` = tokens generated so far (``seq.data.get_output_len()``)."""
+    for req in reqs:
+        if not hasattr(req, "expected_length"):
+            req.expected_length = xpt_expected_length(req.aux_model_score, key, value)
+    return list(sorted(reqs, key=lambda req: req.expected_length - output_len(req)))
 
 
 def age_update(all_pri: Sequence[Req], running_this_step: Sequence[Req]) -> None:

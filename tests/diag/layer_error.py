@@ -1,7 +1,7 @@
 """Diagnostic: per-layer max|hidden - oracle| at the true 125m shape, F16 and F32 modes."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle.opt_scorer import OracleOPTScorer
 from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
 from vllm_ltr_amd.scorer import HipOPTScorer

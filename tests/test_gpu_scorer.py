@@ -239,3 +239,35 @@ def test_plugin_surface(dev):
         assert [g.request_id for g in order] == [m.request_id for m in lit]
         assert [(g.pri, g.idle, g.runs) for g in groups] == [(m.pri, m.idle, m.runs) for m in mirror]
     assert ranker.stats["aux_calls"] == 1                   # scored once, cached (sequence.py:461-465)
+
+
+def test_plugin_tpt_and_xpt_orders(dev):
+    """tpt (class-mode score, string request-id tiebreak, scheduler.py:948) and xpt (expected-length
+    table + SRTF key, scheduler.py:910-933) through the plug-in against the literal expressions."""
+    from oracle import rank_step as rs
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+
+    spec = OPTSpec.tiny_pre_ln(10)                          # class mode: many exact score ties
+    ckpt = seeded_checkpoint(spec, 9)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    r = np.random.RandomState(3)
+    groups = [FakeSeqGroup(str(i), [2] + r.randint(4, spec.vocab_size, r.randint(1, 60)).tolist()) for i in range(120)]
+    ranker = MI355XRanker(sc, "tpt-class", max_length=100, mtype="class")
+    ranker.obtain_aux_scores(groups)
+    got = ranker.order(groups, "tpt")
+    mirror = [rs.Req(g.request_id, g.aux_model_score) for g in groups]
+    assert [g.request_id for g in got] == [m.request_id for m in rs.tpt_order(mirror)]
+    assert len({g.aux_model_score for g in groups}) < len(groups)      # ties were exercised
+
+    key = [-3.0, -1.0, 0.0, 1.0, 2.5]
+    value = [900, 400, 150, 60, 20]
+    xr = MI355XRanker(sc, "opt", max_length=100, mtype="class", xpt_distribution=(key, value))
+    for g in groups:
+        g.output_len = int(r.randint(0, 50))
+    got = xr.order(groups, "xpt")
+    mirror = [rs.Req(g.request_id, g.aux_model_score) for g in groups]
+    for m, g in zip(mirror, groups):
+        m.output_len = g.output_len
+    want = rs.xpt_order(mirror, key, value, lambda q: q.output_len)
+    assert [g.request_id for g in got] == [m.request_id for m in want]

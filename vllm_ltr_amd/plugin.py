@@ -53,7 +53,8 @@ def _string_rank(request_ids: Sequence[str]) -> np.ndarray:
 
 class MI355XRanker:
     def __init__(self, scorer: HipOPTScorer, schedule_type: str = "opt", max_length: int = 2048,
-                 tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank"):
+                 tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank",
+                 xpt_distribution=None):
         """
         scorer      the HBM-resident predictor
         schedule_type  the reference's schedule string (``opt-...-starv<S>-period<P>``)
@@ -71,6 +72,8 @@ class MI355XRanker:
         self.max_length = int(max_length)
         self.tokenize = tokenize
         self.mtype = mtype
+        # xpt policy: (key, value) score -> expected-length table, scheduler.py:312 (torch.load(...))
+        self.xpt_distribution = xpt_distribution
         if mtype == "rank" and scorer.spec.num_labels != 1:
             raise ValueError("mtype 'rank' needs num_labels == 1 (prefill_predictor.py:35-36)")
         self._ws = RankWorkspace(self.device)
@@ -132,7 +135,11 @@ class MI355XRanker:
         t0 = time.perf_counter()
         policy = policy or self.st.policy
         starv, period = (self.st.starv, self.st.period) if policy == "opt" else (-1, 0)
-        score = torch.from_numpy(np.fromiter((r.aux_model_score for r in reqs), np.float32, n)).to(self.device)
+        if policy == "xpt":                                                      # scheduler.py:910-933
+            keys = np.fromiter((self._xpt_key(r) for r in reqs), np.float32, n)
+            score = torch.from_numpy(keys).to(self.device)
+        else:
+            score = torch.from_numpy(np.fromiter((r.aux_model_score for r in reqs), np.float32, n)).to(self.device)
         pri = idle = runs = None
         if starv != -1:
             st = np.empty((3, n), np.int32)
@@ -141,7 +148,7 @@ class MI355XRanker:
             dev = torch.from_numpy(st).to(self.device)
             pri, idle, runs = dev[0], dev[1], dev[2]
         tiebreak = None
-        ascending = policy in ("ropt", "rtpt")                                   # scheduler.py:961,1015
+        ascending = policy in ("ropt", "rtpt", "xpt")                            # scheduler.py:933,961,1015
         if policy in ("tpt", "rtpt"):                                            # scheduler.py:948,961
             tiebreak = torch.from_numpy(_string_rank([r.request_id for r in reqs])).to(self.device)
         perm = rank_step(score, pri, idle, runs, starv, period, self._ws, tiebreak=tiebreak, ascending=ascending)
@@ -153,6 +160,23 @@ class MI355XRanker:
         self.stats["rank_calls"] += 1
         self.stats["rank_seconds"] += time.perf_counter() - t0
         return [reqs[i] for i in perm_h]
+
+    def _xpt_key(self, req) -> float:
+        """expected_length(score) - output_len, the SRTF key of scheduler.py:920-933.  The table
+        lookup is cached on the request like the reference does (``req.expected_length``)."""
+        if not hasattr(req, "expected_length"):
+            key, value = self.xpt_distribution
+            score = round(-req.aux_model_score, 2)
+            req.expected_length = -10000
+            for kid in range(len(key) - 1, -1, -1):
+                if score >= key[kid]:
+                    req.expected_length = value[kid]
+                    break
+        if hasattr(req, "seqs_dict"):
+            out_len = req.seqs_dict[next(iter(req.seqs_dict))].data.get_output_len()
+        else:
+            out_len = getattr(req, "output_len", 0)
+        return float(req.expected_length - out_len)
 
     def ordered_requests(self, scheduler, policy: Optional[str] = None) -> list:
         """scheduler.py:969-1000 (and :936-948, :951-961, :1005-1015 for tpt/rtpt/ropt)."""
@@ -193,5 +217,7 @@ class MI355XRanker:
         scheduler.starv = self.st.starv
         if self.st.starv != -1:
             scheduler.period = self.st.period
-        policy = self.st.policy if self.st.policy in ("opt", "tpt") else "opt"
+        policy = self.st.policy if self.st.policy in ("opt", "tpt", "xpt") else "opt"
+        if policy == "xpt" and self.xpt_distribution is None:
+            raise ValueError("schedule type xpt needs xpt_distribution=(key, value) (scheduler.py:312)")
         scheduler._get_ordered_requests = lambda: self.ordered_requests(scheduler, policy)
