@@ -50,6 +50,11 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise LtrError(f"{LIB_PATH} not found - build it with `python -m vllm_ltr_amd.csrc.build` "
                        "(there is no CPU fallback for the ranking path)")
+    # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7, same as /opt/rocm's).
+    # It must be in the process BEFORE libltr_hip.so is loaded so that the library binds to the
+    # SAME HIP runtime: the stream handles and device pointers handed over come from torch's
+    # runtime, and a second runtime instance does not see them ("no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_size_t
     lib.ltr_abi_version.restype = C.c_int
