@@ -101,6 +101,129 @@ __global__ void __launch_bounds__(256) rank_scatter_kernel(const int32_t* __rest
   if (i < N) perm[rank[i]] = i;
 }
 
+// ---- large queues (N > RK_BUCKET_MIN): sample-sort front end ---------------------------------
+// The counting rank is O(N^2): 10 us at 8k, 0.44 ms at 64k.  Above RK_BUCKET_MIN the keys are first
+// split into 256 buckets by 255 splitters taken from a sorted sample of 2048 keys (the keys are
+// unique, so the buckets are balanced whatever the score distribution or the number of ties), and
+// the counting rank runs inside each bucket only: O(N * N/256).  The order of keys inside a bucket
+// after the atomic scatter is arbitrary, which is harmless: the in-bucket rank depends on the keys
+// alone, so the permutation is the same bit-exact stable order.
+constexpr int RK_BUCKET_MIN = 12288;   // measured crossover: 8k 45 us (counting) vs 62 us; 16k 69 vs 59 us
+constexpr int RK_NBUCKET = 256;
+constexpr int RK_NSAMPLE = 2048;
+
+__global__ void __launch_bounds__(256) rank_sample_kernel(const uint64_t* __restrict__ keys, int N,
+                                                          uint64_t* __restrict__ samp) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < RK_NSAMPLE) samp[k] = keys[(long long)k * N / RK_NSAMPLE];
+}
+
+// splitters: every 8th key of the sorted sample (perm_s = sorted order of samp); also zero the histogram
+__global__ void __launch_bounds__(256) rank_splitters_kernel(const uint64_t* __restrict__ samp,
+                                                             const int32_t* __restrict__ perm_s,
+                                                             uint64_t* __restrict__ spl, int32_t* __restrict__ cnt) {
+  const int k = threadIdx.x;
+  if (k >= 1) spl[k - 1] = samp[perm_s[k * (RK_NSAMPLE / RK_NBUCKET)]];   // spl[0..254]
+  cnt[k] = 0;
+}
+
+// bucket of key = number of splitters <= key; slot = arrival order inside the bucket.
+// 4096 keys per workgroup are first counted in an LDS histogram, then ONE global atomic per
+// (workgroup, non-empty bucket) reserves a range: ~16x fewer same-address atomics than one per key.
+constexpr int RK_ASSIGN_THREADS = 1024, RK_ASSIGN_KEYS = 4;
+__global__ void __launch_bounds__(RK_ASSIGN_THREADS) rank_assign_kernel(
+    const uint64_t* __restrict__ keys, int N, const uint64_t* __restrict__ spl, int32_t* __restrict__ cnt,
+    uint8_t* __restrict__ bid, int32_t* __restrict__ slot) {
+  __shared__ uint64_t s_spl[RK_NBUCKET];
+  __shared__ int s_cnt[RK_NBUCKET];
+  __shared__ int s_base[RK_NBUCKET];
+  const int tid = threadIdx.x;
+  if (tid < RK_NBUCKET - 1) s_spl[tid] = spl[tid];
+  if (tid < RK_NBUCKET) s_cnt[tid] = 0;
+  __syncthreads();
+  int myb[RK_ASSIGN_KEYS], mys[RK_ASSIGN_KEYS];
+#pragma unroll
+  for (int q = 0; q < RK_ASSIGN_KEYS; ++q) {
+    const int i = (blockIdx.x * RK_ASSIGN_KEYS + q) * RK_ASSIGN_THREADS + tid;
+    myb[q] = -1;
+    if (i < N) {
+      const uint64_t k = keys[i];
+      int lo = 0, hi = RK_NBUCKET - 1;          // answer = #splitters <= k, in [0, 255]
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_spl[mid] <= k) lo = mid + 1; else hi = mid;
+      }
+      myb[q] = lo;
+      mys[q] = atomicAdd(&s_cnt[lo], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < RK_NBUCKET) s_base[tid] = s_cnt[tid] ? atomicAdd(&cnt[tid], s_cnt[tid]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < RK_ASSIGN_KEYS; ++q) {
+    const int i = (blockIdx.x * RK_ASSIGN_KEYS + q) * RK_ASSIGN_THREADS + tid;
+    if (myb[q] >= 0) { bid[i] = (uint8_t)myb[q]; slot[i] = s_base[myb[q]] + mys[q]; }
+  }
+}
+
+__global__ void __launch_bounds__(256) rank_bucket_scan_kernel(const int32_t* __restrict__ cnt,
+                                                               int32_t* __restrict__ off) {
+  __shared__ int s[RK_NBUCKET];
+  const int k = threadIdx.x;
+  s[k] = cnt[k];
+  __syncthreads();
+  for (int d = 1; d < RK_NBUCKET; d <<= 1) {
+    const int v = k >= d ? s[k - d] : 0;
+    __syncthreads();
+    s[k] += v;
+    __syncthreads();
+  }
+  off[k + 1] = s[k];
+  if (k == 0) off[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) rank_bucket_scatter_kernel(const uint64_t* __restrict__ keys, int N,
+                                                                  const uint8_t* __restrict__ bid,
+                                                                  const int32_t* __restrict__ slot,
+                                                                  const int32_t* __restrict__ off,
+                                                                  uint64_t* __restrict__ bkeys,
+                                                                  int32_t* __restrict__ bidx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int p = off[bid[i]] + slot[i];
+  bkeys[p] = keys[i];
+  bidx[p] = i;
+}
+
+// one workgroup per bucket: rank inside the bucket by counting, keys staged through LDS
+__global__ void __launch_bounds__(256) rank_in_bucket_kernel(const uint64_t* __restrict__ bkeys,
+                                                             const int32_t* __restrict__ bidx,
+                                                             const int32_t* __restrict__ off,
+                                                             int32_t* __restrict__ perm) {
+  __shared__ uint64_t sk[RK_CHUNK];
+  const int b = blockIdx.x;
+  const int beg = off[b], end = off[b + 1];
+  for (int e0 = beg; e0 < end; e0 += 256) {              // 256 elements per sweep (one per thread)
+    const int e = e0 + threadIdx.x;
+    const uint64_t ke = e < end ? bkeys[e] : 0ull;
+    int cntl = 0;
+    for (int j0 = beg; j0 < end; j0 += RK_CHUNK) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RK_CHUNK / 256; ++r) {
+        const int j = j0 + r * 256 + threadIdx.x;
+        sk[r * 256 + threadIdx.x] = j < end ? bkeys[j] : ~0ull;
+      }
+      __syncthreads();
+      const int lim = (min(RK_CHUNK, end - j0) + 15) & ~15;   // the tail is padded with ~0: never < ke
+#pragma unroll 16
+      for (int jj = 0; jj < lim; ++jj) cntl += (sk[jj] < ke) ? 1 : 0;
+    }
+    if (e < end) perm[beg + cntl] = bidx[e];
+  }
+}
+
 // scheduler.py:1358-1365
 __global__ void __launch_bounds__(256) age_update_kernel(const uint8_t* __restrict__ ran,
                                                          int32_t* __restrict__ pri, int32_t* __restrict__ idle,
@@ -163,20 +286,31 @@ __global__ void __launch_bounds__(BP_THREADS) budget_prefix_kernel(
     if (first_bad < N) break;   // uniform: read after the barrier
   }
   __syncthreads();
-  const int nsel = first_bad;
-  if (tid == 0) *n_sel = nsel;
-  for (int k = tid; k < N; k += BP_THREADS) {
-    int r = perm[k];
-    if (ran != nullptr) ran[r] = (k < nsel) ? 1 : 0;
-    if (granted != nullptr && k >= nsel) granted[r] = 0;
-  }
+  if (tid == 0) *n_sel = first_bad;
+}
+
+// second phase on the whole chip: ran[perm[k]] = k < n_sel, granted = 0 past the selection
+__global__ void __launch_bounds__(256) budget_mark_kernel(const int32_t* __restrict__ perm, int N,
+                                                          const int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran,
+                                                          int32_t* __restrict__ granted) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const int nsel = *n_sel;
+  const int r = perm[k];
+  if (ran != nullptr) ran[r] = (k < nsel) ? 1 : 0;
+  if (granted != nullptr && k >= nsel) granted[r] = 0;
 }
 
 }  // namespace
 
+// keys u64[n] | rank i32[n] | (bucket path) bkeys u64[n] | bidx i32[n] | slot i32[n] | bid u8[n] |
+// samp u64[4096] | perm_s i32[4096] | spl u64[256] | cnt i32[256] | off i32[257]
 size_t rank_workspace_bytes(int64_t N) {
   int64_t n = (N + 63) / 64 * 64;
-  return (size_t)(n * sizeof(uint64_t) + n * sizeof(int32_t) + 256);
+  size_t b = (size_t)(n * sizeof(uint64_t) + n * sizeof(int32_t) + 256);
+  if (N > RK_BUCKET_MIN)
+    b += (size_t)(n * (8 + 4 + 4 + 1)) + RK_NSAMPLE * (8 + 4) + RK_NBUCKET * (8 + 4) + (RK_NBUCKET + 1) * 4 + 1024;
+  return b;
 }
 
 int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
@@ -202,6 +336,35 @@ int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* 
   rank_prepare_kernel<<<(N + 255) / 256, 256, 0, s>>>(scores, (flags & LTR_RANK_USE_PRI) ? pri : nullptr, idle,
                                                       runs, tiebreak, N, starv, period, flags, keys, rank);
   LTR_LAUNCH_CHECK();
+  if (N > RK_BUCKET_MIN) {
+    char* p = (char*)ws + n64 * (sizeof(uint64_t) + sizeof(int32_t)) + 256;
+    auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    uint64_t* bkeys = (uint64_t*)take(n64 * 8);
+    int32_t* bidx = (int32_t*)take(n64 * 4);
+    int32_t* slot = (int32_t*)take(n64 * 4);
+    uint8_t* bid = (uint8_t*)take(n64);
+    uint64_t* samp = (uint64_t*)take(RK_NSAMPLE * 8);
+    int32_t* perm_s = (int32_t*)take(RK_NSAMPLE * 4);
+    uint64_t* spl = (uint64_t*)take(RK_NBUCKET * 8);
+    int32_t* cnt = (int32_t*)take(RK_NBUCKET * 4);
+    int32_t* off = (int32_t*)take((RK_NBUCKET + 1) * 4);
+    rank_sample_kernel<<<RK_NSAMPLE / 256, 256, 0, s>>>(keys, N, samp);
+    LTR_LAUNCH_CHECK();
+    rank_count_kernel<true><<<dim3(RK_NSAMPLE / RK_ITILE, 1), RK_THREADS, 0, s>>>(samp, RK_NSAMPLE, RK_NSAMPLE, rank, perm_s);
+    LTR_LAUNCH_CHECK();
+    rank_splitters_kernel<<<1, RK_NBUCKET, 0, s>>>(samp, perm_s, spl, cnt);
+    LTR_LAUNCH_CHECK();
+    rank_assign_kernel<<<(N + RK_ASSIGN_THREADS * RK_ASSIGN_KEYS - 1) / (RK_ASSIGN_THREADS * RK_ASSIGN_KEYS), RK_ASSIGN_THREADS, 0, s>>>(
+        keys, N, spl, cnt, bid, slot);
+    LTR_LAUNCH_CHECK();
+    rank_bucket_scan_kernel<<<1, RK_NBUCKET, 0, s>>>(cnt, off);
+    LTR_LAUNCH_CHECK();
+    rank_bucket_scatter_kernel<<<(N + 255) / 256, 256, 0, s>>>(keys, N, bid, slot, off, bkeys, bidx);
+    LTR_LAUNCH_CHECK();
+    rank_in_bucket_kernel<<<RK_NBUCKET, 256, 0, s>>>(bkeys, bidx, off, perm_out);
+    LTR_LAUNCH_CHECK();
+    return LTR_OK;
+  }
   const int itiles = (N + RK_ITILE - 1) / RK_ITILE;
   // spread the j range so that the grid holds >= ~512 workgroups; slices are multiples of the chunk
   int js = 1;
@@ -233,6 +396,10 @@ int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const i
   budget_prefix_kernel<<<1, BP_THREADS, 0, s>>>(perm, new_tokens, new_seqs, N, (long long)token_budget,
                                                 (long long)max_seqs, n_sel, ran, granted);
   LTR_LAUNCH_CHECK();
+  if (N > 0 && (ran != nullptr || granted != nullptr)) {
+    budget_mark_kernel<<<(N + 255) / 256, 256, 0, s>>>(perm, N, n_sel, ran, granted);
+    LTR_LAUNCH_CHECK();
+  }
   return LTR_OK;
 }
 

@@ -78,9 +78,10 @@ def budget_prefix(perm: torch.Tensor, new_tokens: torch.Tensor, new_seqs: torch.
     Returns (n_selected int32[1] device tensor, ran uint8[N] | None, granted int32[N] | None)."""
     N = perm.numel()
     dev = perm.device
-    n_sel = torch.zeros(1, dtype=torch.int32, device=dev)
-    ran = torch.zeros(N, dtype=torch.uint8, device=dev) if want_ran else None
-    granted = torch.zeros(N, dtype=torch.int32, device=dev) if want_granted else None
+    # the kernel writes every element of its outputs: no zero-fill launches
+    n_sel = torch.empty(1, dtype=torch.int32, device=dev)
+    ran = torch.empty(N, dtype=torch.uint8, device=dev) if want_ran else None
+    granted = torch.empty(N, dtype=torch.int32, device=dev) if want_granted else None
     lib = _lib.load()
     _lib.check(lib.ltr_budget_prefix(perm.data_ptr(), new_tokens.data_ptr(), new_seqs.data_ptr(), N,
                                      int(token_budget), int(max_num_seqs), n_sel.data_ptr(),
