@@ -250,7 +250,7 @@ def steps_fixture():
         sgs = [_mk_sg(r, plen) for r in ids]
         by_id = {g.request_id: g for g in sgs}
         arrive_at = np.zeros(n, np.int32) if fi == 0 else np.sort(rs.randint(0, steps // 2, n)).astype(np.int32)
-        orders, rans, states, present = [], [], [], []
+        orders, rans, states, present, needs, nseqs, grants = [], [], [], [], [], [], []
         captured = {}
         inner = s._get_ordered_requests
 
@@ -262,8 +262,19 @@ def steps_fixture():
         for step in range(steps):
             for i in np.nonzero(arrive_at == step)[0]:
                 s.add_seq_group(sgs[i])
+            # what the budget walk will see: un-chunked new tokens / new sequences per queued request
+            # (_get_num_new_tokens before the min() with the remaining budget, scheduler.py:1878-1881)
+            nd = np.zeros(n, np.int32); nq = np.zeros(n, np.int32)
+            for g in list(s.waiting) + list(s.running) + list(s.swapped):
+                nd[int(g.request_id)] = sum(q.get_num_new_tokens() for q in g.get_seqs())
+                nq[int(g.request_id)] = g.get_max_num_running_seqs()
+            needs.append(nd); nseqs.append(nq)
             metas, out = s.schedule()
             ran = [x.seq_group.request_id for x in out.scheduled_seq_groups]
+            gr = np.zeros(n, np.int32)
+            for x, meta in zip(out.scheduled_seq_groups, metas):
+                gr[int(x.seq_group.request_id)] = meta.token_chunk_size      # tokens granted this step
+            grants.append(gr)
             for x, meta in zip(out.scheduled_seq_groups, metas):
                 x.seq_group.update_num_computed_tokens(meta.token_chunk_size)
                 if not x.seq_group.is_prefill():
@@ -285,7 +296,9 @@ def steps_fixture():
         runs_out.update({f"f{fi}_score": sc, f"f{fi}_starv": np.int64(starv), f"f{fi}_period": np.int64(period),
                          f"f{fi}_arrive_at": arrive_at, f"f{fi}_orders": np.stack(orders),
                          f"f{fi}_ran": np.stack(rans), f"f{fi}_present": np.stack(present),
-                         f"f{fi}_states": np.stack(states)})
+                         f"f{fi}_states": np.stack(states), f"f{fi}_need_tokens": np.stack(needs),
+                         f"f{fi}_need_seqs": np.stack(nseqs), f"f{fi}_granted": np.stack(grants), f"f{fi}_token_budget": np.int64(max_tokens),
+                         f"f{fi}_max_num_seqs": np.int64(max_seqs)})
     runs_out["n_cases"] = np.int64(3)
     np.savez_compressed(os.path.join(GOLD, "rank_steps.npz"), **runs_out)
 

@@ -163,3 +163,28 @@ def test_budget_prefix(dev, n, budget, max_seqs):
     ran = ran.cpu().numpy(); granted = granted.cpu().numpy()
     assert (ran[perm[:want_n]] == 1).all() and ran.sum() == want_n
     assert granted[perm[:want_n]].tolist() == want_g and granted.sum() == sum(want_g)
+
+
+def test_budget_prefix_vs_reference_schedule(dev):
+    """ltr_budget_prefix on the orders / needs the reference's schedule() saw: same selected set,
+    same granted chunk sizes (tests/golden/rank_steps.npz)."""
+    from vllm_ltr_amd.rank import budget_prefix
+    z = np.load(os.path.join(GOLDEN, "rank_steps.npz"))
+    for fi in range(int(z["n_cases"])):
+        g = lambda k: z[f"f{fi}_{k}"]
+        B, S = int(g("token_budget")), int(g("max_num_seqs"))
+        for step in range(g("orders").shape[0]):
+            o = g("orders")[step]
+            o = o[o >= 0].astype(np.int32)
+            if len(o) == 0:
+                continue
+            need = torch.from_numpy(g("need_tokens")[step].astype(np.int32)).to(dev)
+            seqs = torch.from_numpy(g("need_seqs")[step].astype(np.int32)).to(dev)
+            # perm indexes requests directly (ids are 0..n-1); pad-free: only queued ids appear in o
+            nsel, ran, granted = budget_prefix(torch.from_numpy(o).to(dev), need, seqs, B, S)
+            n = int(nsel.item())
+            want = np.nonzero(g("ran")[step])[0]
+            assert sorted(o[:n].tolist()) == want.tolist(), (fi, step)
+            gr = granted.cpu().numpy()
+            assert gr[o[:n]].tolist() == g("granted")[step][o[:n]].tolist(), (fi, step)
+            assert (ran.cpu().numpy()[o[:n]] == 1).all() and (ran.cpu().numpy()[o[n:]] == 0).all()

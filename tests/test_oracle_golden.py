@@ -161,3 +161,18 @@ def test_literal_vs_numpy_large_random():
         rs.age_update(reqs, [reqs[i] for i in np.nonzero(ranmask)[0]])
         rs.age_update_np(ranmask, pri, idle, runs)
         assert [(q.pri, q.idle, q.runs) for q in reqs] == list(zip(pri.tolist(), idle.tolist(), runs.tolist()))
+
+
+def test_budget_walk_matches_reference_schedule():
+    """The budget-walk restatement (next row) against the reference's own
+    schedule() runs: selected set and granted chunk sizes at every step."""
+    z = np.load(os.path.join(GOLDEN, "rank_steps.npz"), allow_pickle=False)
+    for fi in range(int(z["n_cases"])):
+        g = lambda k: z[f"f{fi}_{k}"]
+        B, S = int(g("token_budget")), int(g("max_num_seqs"))
+        for step in range(g("orders").shape[0]):
+            o = g("orders")[step]
+            o = o[o >= 0]
+            nsel, granted = rs.budget_walk(g("need_tokens")[step][o], g("need_seqs")[step][o], B, S)
+            assert set(o[:nsel].tolist()) == set(np.nonzero(g("ran")[step])[0].tolist()), (fi, step)
+            assert granted == g("granted")[step][o[:nsel]].tolist(), (fi, step)

@@ -77,11 +77,13 @@ def budget_prefix(perm: torch.Tensor, new_tokens: torch.Tensor, new_seqs: torch.
     """Selection of the budget walk over the ranked order (scheduler.py:1137-1211).
     Returns (n_selected int32[1] device tensor, ran uint8[N] | None, granted int32[N] | None)."""
     N = perm.numel()
+    n_req = new_tokens.numel()            # perm holds request indices < n_req (N <= n_req are queued)
     dev = perm.device
-    # the kernel writes every element of its outputs: no zero-fill launches
+    # when every request is queued the kernel writes every output element: no zero-fill launches
+    alloc = torch.empty if n_req == N else torch.zeros
     n_sel = torch.empty(1, dtype=torch.int32, device=dev)
-    ran = torch.empty(N, dtype=torch.uint8, device=dev) if want_ran else None
-    granted = torch.empty(N, dtype=torch.int32, device=dev) if want_granted else None
+    ran = alloc(n_req, dtype=torch.uint8, device=dev) if want_ran else None
+    granted = alloc(n_req, dtype=torch.int32, device=dev) if want_granted else None
     lib = _lib.load()
     _lib.check(lib.ltr_budget_prefix(perm.data_ptr(), new_tokens.data_ptr(), new_seqs.data_ptr(), N,
                                      int(token_budget), int(max_num_seqs), n_sel.data_ptr(),
