@@ -178,6 +178,34 @@ int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* run
 int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int32_t N,
                    void* stream);
 
+/* Next row in scope: the hidden-state learning-to-rank head of
+ * vllm/model_executor/predictor.py - FCModel (:10-43: optional input LayerNorm, then
+ * activation(Linear) per layer), OutputLayer (:91-125) and LTRModel.score (:78-89, sum over
+ * d_output) - applied to the backbone's hidden states at the selected tokens (opt.py:250-255;
+ * loaded in model_loader/loader.py:234-241 from PredictorConfig, config_predictor.py:78-117).
+ * Weight pointers: [0] input_norm.weight f32 | NULL, [1] input_norm.bias f32 | NULL, then per
+ * dense layer (the n_fc FC layers, then output_layer.w_1): weight [out, in] in weight_dtype,
+ * bias [out] f32. */
+enum { LTR_ACT_NONE = 0, LTR_ACT_RELU = 1, LTR_ACT_SIGMOID = 2, LTR_ACT_TANH = 3, LTR_ACT_GELU = 4, LTR_ACT_SILU = 5 };
+typedef struct ltr_head_desc {
+  int32_t n_features;         /* ModelConfig.n_features */
+  int32_t n_fc;               /* len(FCConfig.sizes), 0 when fc_model is null */
+  int32_t fc_sizes[8];
+  int32_t input_norm;         /* FCConfig.input_norm */
+  int32_t activation;         /* FCConfig.activation -> LTR_ACT_* */
+  int32_t d_output;           /* PostModelConfig.d_output */
+  int32_t output_activation;  /* PostModelConfig.output_activation -> LTR_ACT_* */
+  int32_t weight_dtype;       /* LTR_W_F32 | LTR_W_F16 */
+} ltr_head_desc;
+typedef struct ltr_head_model* ltr_head_handle;
+int ltr_head_create(const ltr_head_desc* desc, const void* const* weights, int32_t n_weights,
+                    ltr_head_handle* out);
+int ltr_head_destroy(ltr_head_handle h);
+/* hidden f32 [rows, n_features]; row_index int32 [N] selects the rows to score (NULL: rows 0..N-1,
+ * the index_select of opt.py:252-254); scores_out f32 [N]. */
+int ltr_head_score(ltr_head_handle h, const float* hidden, const int32_t* row_index, int32_t N,
+                   float* scores_out, void* stream);
+
 /* Per-kernel-class timing for the roofline report (bench.py).  When enabled, ltr_score /
  * ltr_forward_hidden bracket every launch with HIP events on the caller's stream (no host
  * sync); ltr_profile_read synchronises on the last event, sums event-to-event durations

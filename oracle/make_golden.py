@@ -18,6 +18,7 @@ process group (vllm/distributed/parallel_state.py:52-77).
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import sys
 import time
@@ -326,6 +327,32 @@ def config_fixture():
     print("config cases:", list(out), sts)
 
 
+def ltr_head_fixture():
+    """The reference's own predictor_model (vllm/model_executor/predictor.py:128-145) with seeded
+    weights loaded through load_state_dict, scored on random hidden states."""
+    import copy
+    from vllm.model_executor.predictor import predictor_model
+    from oracle.ltr_head import seeded_head_weights
+    cases = [
+        ("small_relu", 256, dict(sizes=[128, 64], input_norm=True, activation="ReLU", dropout=0.1), dict(d_output=1, output_activation=None), 37),
+        ("wide_tanh_sum", 4096, dict(sizes=[1024], input_norm=True, activation="Tanh", dropout=None), dict(d_output=4, output_activation="Sigmoid"), 41),
+        ("no_fc", 512, None, dict(d_output=1, output_activation=None), 43),
+        ("gelu_nonorm", 768, dict(sizes=[96, 200], input_norm=False, activation="GELU", dropout=None), dict(d_output=3, output_activation="Tanh"), 47),
+    ]
+    for name, nf, fc, post, seed in cases:
+        sd = seeded_head_weights(nf, fc["sizes"] if fc else None, bool(fc and fc["input_norm"]), post["d_output"], seed)
+        m = predictor_model(fc_model=copy.deepcopy(fc), post_model=dict(post), n_features=nf, pred_layer_idx=31).eval().float()
+        m.load_state_dict({k: torch.from_numpy(v.astype(np.float32)) for k, v in sd.items()})
+        x = (np.random.RandomState(seed + 1).standard_normal((40, nf)) * 1.5).astype(np.float32)
+        with torch.no_grad():
+            y = m.score(torch.from_numpy(x))
+        y = y.reshape(40, -1)[:, 0].float().numpy() if post["d_output"] == 1 else y.float().numpy()
+        np.savez_compressed(os.path.join(GOLD, f"ltr_head_{name}.npz"), x=x, score=y.astype(np.float32),
+                            n_features=np.int64(nf), seed=np.int64(seed),
+                            cfg=np.array(json.dumps(dict(fc_model=fc, post_model=post))))
+        print(f"ltr_head {name}: n_features={nf} score[:3]={y[:3]}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also the true-shape 125m / 350m cases")
@@ -340,6 +367,8 @@ if __name__ == "__main__":
         order_fixture()
     if args.only in ("", "steps"):
         steps_fixture()
+    if args.only in ("", "head"):
+        ltr_head_fixture()
     if args.only in ("", "score"):
         edge = [1, 2, 4, 5, 63, 64, 65, 100, 3, 128, 17, 1, 31, 32, 33, 150]
         score_fixture("tiny_pre_ln", OPTSpec.tiny_pre_ln(), edge, 11)

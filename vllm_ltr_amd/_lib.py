@@ -20,7 +20,8 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 # every symbol include/ltr_hip.h declares (tests check the library exports them all)
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
            "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
-           "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read")
+           "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
+           "ltr_head_create", "ltr_head_destroy", "ltr_head_score")
 
 
 class LtrError(RuntimeError):
@@ -31,6 +32,15 @@ class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "hidden_size", "ffn_dim", "num_layers", "num_heads", "word_embed_proj_dim",
         "pos_rows", "num_labels", "pre_ln", "weight_dtype")]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("n_fc", C.c_int32), ("fc_sizes", C.c_int32 * 8),
+                ("input_norm", C.c_int32), ("activation", C.c_int32), ("d_output", C.c_int32),
+                ("output_activation", C.c_int32), ("weight_dtype", C.c_int32)]
+
+
+ACTIVATIONS = {None: 0, "Identity": 0, "ReLU": 1, "Sigmoid": 2, "Tanh": 3, "GELU": 4, "SiLU": 5}
 
 
 class ProfileStats(C.Structure):
@@ -73,6 +83,9 @@ def load() -> C.CDLL:
     lib.ltr_budget_prefix.argtypes = [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp]
     lib.ltr_profile_enable.argtypes = [vp, i32]
     lib.ltr_profile_read.argtypes = [vp, C.POINTER(ProfileStats), i32]
+    lib.ltr_head_create.argtypes = [C.POINTER(HeadDesc), C.POINTER(vp), i32, C.POINTER(vp)]
+    lib.ltr_head_destroy.argtypes = [vp]
+    lib.ltr_head_score.argtypes = [vp, vp, vp, i32, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version"):

@@ -44,3 +44,44 @@ class PrefillPredictorConfig:
         content = {"model": dict(config.model.__dict__)}
         with open(config_path, "w") as outfile:
             json.dump(content, outfile)
+
+
+# ---- hidden-state predictor head (vllm/config_predictor.py:17-38, 78-117) ---------------------
+@dataclasses.dataclass
+class FCConfig:
+    sizes: list
+    input_norm: bool
+    activation: Optional[str]
+    dropout: Optional[float]
+
+
+@dataclasses.dataclass
+class PostModelConfig:
+    d_output: int
+    output_activation: Optional[str]
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    fc_model: Optional[dict]          # kept as the raw dict like the reference (it is **-expanded later)
+    transformer: Optional[dict]
+    post_model: dict
+    path: str = ""
+    n_features: int = 4096
+    pred_layer_idx: int = 31
+
+
+@dataclasses.dataclass
+class PredictorConfig:
+    model: ModelConfig
+
+    @classmethod
+    def from_json(cls, config_path):
+        with open(config_path) as config_file:
+            return PredictorConfig.from_dict(json.load(config_file))
+
+    @classmethod
+    def from_dict(cls, config):
+        config = dict(config)
+        config["model"] = ModelConfig(**config["model"])
+        return cls(**config)
