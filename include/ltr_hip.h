@@ -92,7 +92,10 @@ const char* ltr_last_error(void);
 /* Replaces loading the AUX engine's model: AUXLLM(...) -> Worker.load_model ->
  * OPTForSequenceClassification.load_weights (vllm/engine/llm_engine.py:224-240,
  * vllm/model_executor/models/opt.py:411-444).  The library keeps the POINTERS (the
- * caller owns the weight memory and must keep it alive until ltr_destroy). */
+ * caller owns the weight memory and must keep it alive until ltr_destroy).  With
+ * LTR_W_F16 the dense-layer weights (QKV / out_proj / fc1 / fc2 / project_in) are also
+ * copied once, on the default stream, into a library-owned GEMM-friendly layout: the
+ * buffers must hold the final values when ltr_create is called. */
 int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights,
                ltr_handle* out);
 int ltr_destroy(ltr_handle h);

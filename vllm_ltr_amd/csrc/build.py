@@ -18,7 +18,7 @@ HEADERS = ["ltr_internal.h", os.path.join("..", "..", "include", "ltr_hip.h")]
 LIB = os.path.join(HERE, "libltr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"] + os.environ.get("LTR_HIPCC_EXTRA", "").split()
 
 
 def _stale(target: str, deps) -> bool:

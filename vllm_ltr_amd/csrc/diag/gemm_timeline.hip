@@ -6,7 +6,7 @@
 #include <map>
 #include <vector>
 #include "../ltr_internal.h"
-namespace ltr { int gemm_timeline_read(unsigned long long* host); }
+namespace ltr { int gemm_timeline_read(unsigned long long* host); int gemm_waits_read(unsigned long long* host); }
 using namespace ltr;
 int main() {
   const int M = 65536, N = 2304, K = 768;
@@ -15,7 +15,8 @@ int main() {
   (void)hipMalloc(&ohi, (size_t)M * N * 4); (void)hipMalloc(&bias, N * 4);
   (void)hipMemset(ahi, 0x11, (size_t)M * K * 2); (void)hipMemset(alo, 0x01, (size_t)M * K * 2); (void)hipMemset(w, 0x22, (size_t)N * K * 2);
   (void)hipMemset(bias, 0, N * 4);
-  GemmArgs g{}; g.a = AOp{ahi, alo}; g.w = w; g.bias = bias; g.out_split = AOp{ohi, (char*)ohi + (size_t)M * N * 2}; g.M = M; g.N = N; g.K = K;
+  __half* wp; (void)hipMalloc(&wp, (size_t)N * K * 2); launch_pack_weight(w, wp, N, K, 0);
+  GemmArgs g{}; g.a = AOp{ahi, alo}; g.w = wp; g.bias = bias; g.out_split = AOp{ohi, (char*)ohi + (size_t)M * N * 2}; g.M = M; g.N = N; g.K = K;
   for (int it = 0; it < 3; ++it) launch_gemm(LTR_W_F16, g, 0);
   (void)hipDeviceSynchronize();
   std::vector<unsigned long long> tl(8192 * 4);
@@ -31,6 +32,13 @@ int main() {
     unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7, sh = (hw >> 12) & 1;   // gfx9 HW_ID: CU_ID[11:8], SH_ID[12], SE_ID[15:13]
     by_cu[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back(b);
     main_sum += tl[b * 4 + 1] - tl[b * 4]; epi_sum += tl[b * 4 + 2] - tl[b * 4 + 1];
+  }
+  {
+    std::vector<unsigned long long> wt(8192 * 2);
+    gemm_waits_read(wt.data());
+    double d = 0, b = 0;
+    for (int i = 0; i < std::min(nb, 8192); ++i) { d += wt[i * 2]; b += wt[i * 2 + 1]; }
+    printf("wave0 per block: dma wait %.0f cyc, barrier wait %.0f cyc\n", d / std::min(nb, 8192), b / std::min(nb, 8192));
   }
   printf("blocks %d  CUs seen %zu  avg main %.0f cyc  avg epilogue %.0f cyc\n", nb, by_cu.size(), main_sum / std::min(nb, 8192), epi_sum / std::min(nb, 8192));
   int shown = 0;

@@ -44,12 +44,19 @@ struct ltr_model {
   bool dbg_attn_valu = false;   // LTR_DEBUG_ATTN_VALU=1: f32 VALU attention inside the F16 mode (A/B for accuracy work)
   std::vector<ProfRec> prof;       // records in use
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+  // F16 mode: library-owned slab-major images of the GEMM weights (launch_pack_weight), same index
+  // space as w; F32 mode: wg == w (row-major, used as is)
+  void* packed = nullptr;
+  std::vector<const void*> wg;
   ~ltr_model() {
+    if (packed) (void)hipFree(packed);
     for (auto& r : prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (auto& e : prof_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
   const void* gw(int i) const { return w[i]; }
   const void* lw(int layer, int i) const { return w[LTR_WT_GLOBAL_COUNT + layer * LTR_WL_COUNT + i]; }
+  const void* gemm_gw(int i) const { return wg[i]; }
+  const void* gemm_lw(int layer, int i) const { return wg[LTR_WT_GLOBAL_COUNT + layer * LTR_WL_COUNT + i]; }
 };
 
 namespace {
@@ -147,7 +154,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   if (rc) return rc;
   if (De != H) {   // h = project_in(tok) + pos : GEMM with the position rows as residual (in place)
     GemmArgs g{};
-    g.a = ws.a; g.w = m->gw(LTR_WT_PROJECT_IN); g.bias = nullptr; g.resid = ws.h; g.out_f32 = ws.h;
+    g.a = ws.a; g.w = m->gemm_gw(LTR_WT_PROJECT_IN); g.bias = nullptr; g.resid = ws.h; g.out_f32 = ws.h;
     g.M = Tc; g.N = H; g.K = De;
     if ((rc = gemm(g))) return rc;
   }
@@ -163,7 +170,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     }
     {
       GemmArgs g{};
-      g.a = ws.a; g.w = m->lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
+      g.a = ws.a; g.w = m->gemm_lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
       if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
       g.M = Tc; g.N = 3 * H; g.K = H;
       if ((rc = gemm(g))) return rc;
@@ -191,7 +198,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     }
     {
       GemmArgs g{};
-      g.a = ab; g.w = m->lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
+      g.a = ab; g.w = m->gemm_lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
       if ((rc = gemm(g))) return rc;
     }
@@ -206,13 +213,13 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     }
     {
       GemmArgs g{};
-      g.a = ab; g.w = m->lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
+      g.a = ab; g.w = m->gemm_lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
       g.out_split = fb; g.relu = 1; g.M = Mr; g.N = F; g.K = H;
       if ((rc = gemm(g))) return rc;
     }
     {
       GemmArgs g{};
-      g.a = fb; g.w = m->lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
+      g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F;
       if ((rc = gemm(g))) return rc;
     }
@@ -292,6 +299,38 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
   m->w.assign(weights, weights + want);
   m->chunk_tokens = DEFAULT_CHUNK_TOKENS;
   { const char* e = getenv("LTR_DEBUG_ATTN_VALU"); m->dbg_attn_valu = e && e[0] == '1'; }
+  m->wg = m->w;
+  if (desc->weight_dtype == LTR_W_F16) {
+    // one-time re-layout of the dense-layer weights into the GEMM kernel's slab-major image
+    const size_t H = desc->hidden_size, F = desc->ffn_dim, De = desc->word_embed_proj_dim;
+    struct Item { int idx; size_t n, k; };
+    std::vector<Item> items;
+    if (proj) items.push_back({LTR_WT_PROJECT_IN, H, De});
+    for (int L = 0; L < desc->num_layers; ++L) {
+      const int b = LTR_WT_GLOBAL_COUNT + L * LTR_WL_COUNT;
+      items.push_back({b + LTR_WL_QKV_W, 3 * H, H});
+      items.push_back({b + LTR_WL_OUT_W, H, H});
+      items.push_back({b + LTR_WL_FC1_W, F, H});
+      items.push_back({b + LTR_WL_FC2_W, H, F});
+    }
+    size_t total = 0;
+    for (auto& it : items) total += (it.n * it.k * 2 + 255) / 256 * 256;
+    if (total) {
+      if (hipMalloc(&m->packed, total) != hipSuccess) {
+        delete m;
+        set_error("ltr_create: cannot allocate %zu bytes for the packed weights", total);
+        return LTR_E_NOMEM;
+      }
+      size_t off = 0;
+      for (auto& it : items) {
+        void* dst = (char*)m->packed + off;
+        if ((rc = launch_pack_weight(m->w[it.idx], dst, (int)it.n, (int)it.k, nullptr))) { delete m; return rc; }
+        m->wg[it.idx] = dst;
+        off += (it.n * it.k * 2 + 255) / 256 * 256;
+      }
+      if (hipStreamSynchronize(nullptr) != hipSuccess) { delete m; set_error("ltr_create: weight packing failed"); return LTR_E_HIP; }
+    }
+  }
   *out = m;
   return LTR_OK;
 }

@@ -92,7 +92,11 @@ __device__ __forceinline__ void store_tile(const Epilogue& e, const f32x16& acc,
 // ------------------------------------------------------------------------------------
 // F16 split mode.  K-slab = 32 halves.  Operands go HBM -> LDS directly with
 // global_load_lds_dwordx4 (no VGPR staging, no ds_write): one wave instruction lands 1 KiB
-// = 16 tile rows x 64 B, LDS destination linear (wave base + lane * 16), so the bank
+// = 16 tile rows x 64 B, LDS destination linear (wave base + lane * 16).  The weights are static,
+// so ltr_create re-lays them out once into the SLAB-MAJOR image [K/32][N][32] (pack_weight_kernel):
+// a 16-row group of a K-slab is then 1 KiB of contiguous memory (full 128-B lines) instead of
+// sixteen 64-B half lines (measured -3.5 % GEMM time; L2 -> LDS streams 32 TB/s contiguous vs
+// 18-20 TB/s in 64-B row pieces, diag/dma_rate.hip).  The bank
 // swizzle is applied on the SOURCE side: the lane that fills physical 16-B chunk c of row r
 // fetches logical chunk c ^ ((r >> 2) & 3), and fragment reads apply the same XOR.  With it
 // a ds_read_b128 lane group (rows {0-3,12-15,20-27} / ...) touches 16 distinct 16-B slots of
@@ -118,6 +122,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 #ifdef LTR_GEMM_TIMELINE
 __device__ unsigned long long g_timeline[8192 * 4];
+__device__ unsigned long long g_waits[8192 * 2];
 #endif
 
 __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
@@ -148,16 +153,18 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     for (int i = 0; i < 2; ++i) {
       const int wrow = wave * 32 + i * 16 + (lane >> 2);
       const int wc_log = (lane & 3) ^ ((wrow >> 2) & 3);
-      gw[i] = w + (size_t)min(n0 + wrow, N - 1) * K + wc_log * 8;
+      gw[i] = w + (size_t)min(n0 + wrow, N - 1) * BK16 + wc_log * 8;   // slab-major weight image
     }
   }
+  const size_t w_slab = (size_t)N * BK16;
   auto issue = [&](int stage, int k0) {
     __half* base = smem + stage * STAGE;
-    __builtin_amdgcn_global_load_lds((gbl_void*)(ga + k0), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(gl + k0), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
+    const size_t ka = k0, kw = (size_t)(k0 / BK16) * w_slab;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(ga + ka), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(gw[i] + k0),
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gw[i] + kw),
                                        (lds_void*)(base + 2 * A_PLANE + (wave * 32 + i * 16) * BK16), 16, 0, 0);
   };
 
@@ -171,10 +178,23 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
 
   const int frow = lane & 31, fk = lane >> 5;
   const int nk = K / BK16;
+#ifdef LTR_GEMM_TIMELINE
+  unsigned long long tl_dma = 0, tl_bar = 0;
+#endif
   issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
+#ifdef LTR_GEMM_TIMELINE
+    const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of slab kt have landed
+#ifdef LTR_GEMM_TIMELINE
+    const unsigned long long w1 = __builtin_readcyclecounter();
+#endif
     __syncthreads();                                    // everyone's have; slab kt-1 fully consumed
+#ifdef LTR_GEMM_TIMELINE
+    const unsigned long long w2 = __builtin_readcyclecounter();
+    tl_dma += w1 - w0; tl_bar += w2 - w1;
+#endif
     if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * BK16);
     const __half* s_ahi = smem + (kt & 1) * STAGE;
     const __half* s_alo = s_ahi + A_PLANE;
@@ -285,6 +305,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     g_timeline[blockIdx.x * 4 + 1] = tl1;
     g_timeline[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
     g_timeline[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hwid;
+    g_waits[blockIdx.x * 2] = tl_dma; g_waits[blockIdx.x * 2 + 1] = tl_bar;
   }
 #endif
 }
@@ -370,8 +391,32 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const float* __restric
 }  // namespace
 
 #ifdef LTR_GEMM_TIMELINE
+int gemm_waits_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_waits), sizeof(unsigned long long) * 8192 * 2); }
 int gemm_timeline_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8192 * 4); }
 #endif
+
+namespace {
+// nn.Linear weight [N][K] (K contiguous) -> slab-major image [K/32][N][32]; one 16-B piece per thread
+__global__ void __launch_bounds__(256) pack_weight_kernel(const __half* __restrict__ src, __half* __restrict__ dst, int N,
+                                                          int K) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // piece index in the destination
+  const size_t pieces = (size_t)N * K / 8;
+  if (i >= pieces) return;
+  const int c = (int)(i & 3);                 // 16-B chunk inside the 64-B slab row
+  const size_t rn = i >> 2;                   // slab * N + n
+  const int n = (int)(rn % N), slab = (int)(rn / N);
+  *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(src + (size_t)n * K + slab * BK16 + c * 8);
+}
+
+}  // namespace
+
+int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s) {
+  if (K % BK16) { set_error("pack_weight: K=%d must be a multiple of %d", K, BK16); return LTR_E_INVAL; }
+  const size_t pieces = (size_t)N * K / 8;
+  pack_weight_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>((const __half*)src, (__half*)dst, N, K);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
 
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   if (g.M == 0) return LTR_OK;

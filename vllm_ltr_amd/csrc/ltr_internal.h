@@ -48,7 +48,8 @@ enum OutKind { OUT_F32 = 1, OUT_SPLIT = 2 };
 
 struct GemmArgs {
   AOp a;                 // [M, K]
-  const void* w;         // [N, K] row-major (nn.Linear layout), weight dtype
+  const void* w;         // F32 mode: [N, K] row-major (nn.Linear layout); F16 mode: the slab-major image
+                         // [K/32][N][32] made by launch_pack_weight
   const float* bias;     // [N] or nullptr
   const float* resid;    // f32 [M, N] or nullptr (may alias out_f32: in-place residual add)
   float* out_f32;        // f32 [M, N] or nullptr
@@ -59,6 +60,7 @@ struct GemmArgs {
 
 // launchers (each in its own .hip file)
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
+int launch_pack_weight(const void* src_f16 /*[N,K]*/, void* dst_f16 /*[K/32][N][32]*/, int N, int K, hipStream_t s);
 
 int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
                      float* out_f32 /*nullable, may alias x*/, AOp out_op /*nullable*/, hipStream_t s);
