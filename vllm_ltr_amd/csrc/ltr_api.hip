@@ -159,7 +159,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     if ((rc = gemm(g))) return rc;
   }
   if (!d.pre_ln) {   // post-LN blocks consume h itself as the first GEMM operand
-    if ((rc = launch_to_operand(wd, ws.h, (int64_t)Tc * H, ws.a, s))) return rc;
+    if ((rc = launch_to_operand(wd, ws.h, Tc, H, ws.a, s))) return rc;
   }
   const int nl = n_layers < 0 ? d.num_layers : (n_layers < d.num_layers ? n_layers : d.num_layers);
   for (int L = 0; L < nl; ++L) {
@@ -172,7 +172,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = ws.a; g.w = m->gemm_lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
       if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
-      g.M = Tc; g.N = 3 * H; g.K = H;
+      g.M = Tc; g.N = 3 * H; g.K = H; g.a_slab = wd == LTR_W_F16;   // A from LayerNorm / to_operand
       if ((rc = gemm(g))) return rc;
     }
     {
@@ -214,13 +214,13 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     {
       GemmArgs g{};
       g.a = ab; g.w = m->gemm_lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
-      g.out_split = fb; g.relu = 1; g.M = Mr; g.N = F; g.K = H;
+      g.out_split = fb; g.relu = 1; g.M = Mr; g.N = F; g.K = H; g.a_slab = g.out_slab = wd == LTR_W_F16;
       if ((rc = gemm(g))) return rc;
     }
     {
       GemmArgs g{};
       g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
-      g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F;
+      g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F; g.a_slab = wd == LTR_W_F16;
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {

@@ -58,6 +58,7 @@ struct Epilogue {
   void* out_hi;
   void* out_lo;
   int M, N, relu;
+  int a_slab, out_slab;   // F16 kernel: slab-major A image / slab-major split output (GemmArgs)
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -146,7 +147,8 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
   {
     const int row = wave * 16 + (lane >> 2);
     const int c_log = (lane & 3) ^ ((row >> 2) & 3);
-    const size_t aoff = (size_t)min(m0 + row, M - 1) * K + c_log * 8;   // rows past M/N: any valid row, masked later
+    // rows past M/N: any valid row, masked later.  Row-major: row pitch K; slab-major: row pitch 32, slab pitch M*32
+    const size_t aoff = (size_t)min(m0 + row, M - 1) * (ep.a_slab ? BK16 : K) + c_log * 8;
     ga = a_hi + aoff;
     gl = a_lo + aoff;
 #pragma unroll
@@ -156,10 +158,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
       gw[i] = w + (size_t)min(n0 + wrow, N - 1) * BK16 + wc_log * 8;   // slab-major weight image
     }
   }
-  const size_t w_slab = (size_t)N * BK16;
+  const size_t w_slab = (size_t)N * BK16, a_slab = ep.a_slab ? (size_t)M * BK16 : (size_t)BK16;
   auto issue = [&](int stage, int k0) {
     __half* base = smem + stage * STAGE;
-    const size_t ka = k0, kw = (size_t)(k0 / BK16) * w_slab;
+    const size_t ka = (size_t)(k0 / BK16) * a_slab, kw = (size_t)(k0 / BK16) * w_slab;
     __builtin_amdgcn_global_load_lds((gbl_void*)(ga + ka), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
 #pragma unroll
@@ -253,12 +255,14 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     if (ccol < N) {
       float4 va[2], vb[2], ra[2], rb[2];
       size_t o[2];
+      int gr[2];
       bool ok[2];
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int srow = it * 8 + erow;
         const int grow = m0 + wr * 64 + i * 32 + half * 16 + srow;
         ok[it] = grow < M;
+        gr[it] = grow;
         o[it] = (size_t)grow * N + ccol;
         va[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
         vb[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol + 4);
@@ -288,8 +292,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
           __half h[8], l[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
-          *reinterpret_cast<uint4*>((__half*)ep.out_hi + o[it]) = *reinterpret_cast<const uint4*>(h);
-          *reinterpret_cast<uint4*>((__half*)ep.out_lo + o[it]) = *reinterpret_cast<const uint4*>(l);
+          const size_t os = ep.out_slab ? slab_off(gr[it], ccol, M) : o[it];
+          *reinterpret_cast<uint4*>((__half*)ep.out_hi + os) = *reinterpret_cast<const uint4*>(h);
+          *reinterpret_cast<uint4*>((__half*)ep.out_lo + os) = *reinterpret_cast<const uint4*>(l);
         }
       }
     }
@@ -427,7 +432,9 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   }
   const int bn = wdtype == LTR_W_F16 ? BN16 : BN;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
-  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu};
+  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab};
+  if (wdtype != LTR_W_F16 && (g.a_slab || g.out_slab)) { set_error("gemm: slab-major operands exist in F16 mode only"); return LTR_E_INVAL; }
+  if (g.out_slab && g.N % 32) { set_error("gemm: slab-major output needs N %% 32 == 0"); return LTR_E_INVAL; }
   dim3 grid(tiles_m * tiles_n);
   if (wdtype == LTR_W_F16) {
     gemm_f16s_kernel<<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,

@@ -56,15 +56,20 @@ struct GemmArgs {
   AOp out_split;         // hi/lo planes [M, N] (F16 mode) or f32 copy in .hi (F32 mode); may be null
   int M, N, K;
   int relu;
+  // F16 mode only: operand images in SLAB-MAJOR order, element (row, k) at ((k >> 5) * M + row) * 32 + (k & 31)
+  // halves (every 32-wide K-slab of a 16-row group is 1 KiB of contiguous memory for the LDS DMA).
+  int a_slab;            // A planes are slab-major (written by launch_layernorm / launch_to_operand / a GEMM with out_slab)
+  int out_slab;          // write out_split slab-major (it is the next GEMM's A operand)
 };
 
 // launchers (each in its own .hip file)
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
 int launch_pack_weight(const void* src_f16 /*[N,K]*/, void* dst_f16 /*[K/32][N][32]*/, int N, int K, hipStream_t s);
 
+// out_op: F16 mode -> slab-major hi|lo image (GemmArgs::a_slab); F32 mode -> row-major f32 copy
 int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
                      float* out_f32 /*nullable, may alias x*/, AOp out_op /*nullable*/, hipStream_t s);
-int launch_to_operand(int wdtype, const float* x, int64_t n, AOp out, hipStream_t s);
+int launch_to_operand(int wdtype, const float* x, int M, int H, AOp out, hipStream_t s);
 // compact the last-token rows (cu[i+1]-1-tok_off) of the f32 stream and of an operand buffer to [n_req, H]
 int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_req, int H, const float* h_src, AOp a_src,
                             float* h_dst, AOp a_dst, hipStream_t s);
@@ -99,6 +104,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32-lane half this lane is in
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -110,6 +120,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // x*y, hipcc contracts `a - hi` into v_fma_mix(x, y, -hi) (exact product) while the stored
 // hi comes from the f32-ROUNDED product, and in near-tie cases the two disagree by one
 // fp16 ulp with the wrong-signed lo (measured: isolated 2^-12 errors in the attention output).
+// offset (halves) of element (row, col) in a slab-major operand image with ld rows
+__device__ __forceinline__ size_t slab_off(int row, int col, int ld) {
+  return ((size_t)(col >> 5) * ld + row) * 32 + (col & 31);
+}
+
 __device__ __forceinline__ void split_f16(float a, __half& hi, __half& lo) {
   asm volatile("" : "+v"(a));
   hi = __float2half_rn(a);

@@ -90,20 +90,23 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(
 }
 
 // y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance, per row.
-// MAXV = ceil(H / 512) register chunks of 8 floats per lane.
+// HALF a wave (32 lanes) owns one row, MAXV = ceil(H / 256) register chunks of 8 floats per lane:
+// lanes 0-31 hold row 2w, lanes 32-63 row 2w+1, so one store instruction writes, for every
+// 32-column slab it touches, the 64-B pieces of two ADJACENT rows = one full 128-B line of the
+// slab-major operand image (one row per wave left half-line writes: 17.5 -> 20.5 ms per step).
 template <bool SPLIT, int MAXV>
 __global__ void __launch_bounds__(256) layernorm_kernel(
     const float* x /* may alias out_f32 */, const float* __restrict__ gamma, const float* __restrict__ beta, int M,
     int H, float* out_f32, void* out_hi, void* out_lo) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 31;
+  const int row = blockIdx.x * (2 * ROWS_PER_BLOCK) + (threadIdx.x >> 5);
   if (row >= M) return;
   const float* xr = x + (size_t)row * H;
   float v[MAXV][8];
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
-    int c = k * 512 + lane * 8;
+    int c = k * 256 + lane * 8;
     if (c < H) {
       Vec8<float>::load(xr + c, v[k]);
 #pragma unroll
@@ -113,20 +116,20 @@ __global__ void __launch_bounds__(256) layernorm_kernel(
       for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
     }
   }
-  const float mean = wave_sum(sum) / (float)H;
+  const float mean = half_wave_sum(sum) / (float)H;
   float sq = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
-    int c = k * 512 + lane * 8;
+    int c = k * 256 + lane * 8;
     if (c < H) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) { float d = v[k][i] - mean; sq += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)H + LN_EPS);
+  const float rstd = rsqrtf(half_wave_sum(sq) / (float)H + LN_EPS);
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
-    int c = k * 512 + lane * 8;
+    int c = k * 256 + lane * 8;
     if (c < H) {
       float g[8], b[8], y[8];
       Vec8<float>::load(gamma + c, g);
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(
       for (int i = 0; i < 8; ++i) y[i] = (v[k][i] - mean) * rstd * g[i] + b[i];
       if (out_f32) store8_f32(out_f32 + (size_t)row * H + c, y);
       if (out_hi) {
-        if (SPLIT) store8_split((__half*)out_hi + (size_t)row * H + c, (__half*)out_lo + (size_t)row * H + c, y);
+        if (SPLIT) { const size_t o = slab_off(row, c, M); store8_split((__half*)out_hi + o, (__half*)out_lo + o, y); }
         else store8_f32((float*)out_hi + (size_t)row * H + c, y);
       }
     }
@@ -170,13 +173,18 @@ __global__ void __launch_bounds__(256) gather_last_rows_kernel(const int32_t* __
 }
 
 template <bool SPLIT>
-__global__ void __launch_bounds__(256) to_operand_kernel(const float* __restrict__ x, int64_t n8, void* hi,
+__global__ void __launch_bounds__(256) to_operand_kernel(const float* __restrict__ x, int M, int H8, void* hi,
                                                          void* lo) {
+  const int64_t n8 = (int64_t)M * H8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     float v[8];
     Vec8<float>::load(x + i * 8, v);
-    if (SPLIT) store8_split((__half*)hi + i * 8, (__half*)lo + i * 8, v);
-    else store8_f32((float*)hi + i * 8, v);
+    if (SPLIT) {
+      const size_t o = slab_off((int)(i / H8), (int)(i % H8) * 8, M);
+      store8_split((__half*)hi + o, (__half*)lo + o, v);
+    } else {
+      store8_f32((float*)hi + i * 8, v);
+    }
   }
 }
 
@@ -203,16 +211,16 @@ int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N
 int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
                      float* out_f32, AOp out_op, hipStream_t s) {
   if (M == 0) return LTR_OK;
-  if (H % 8 || H > 2048) { set_error("layernorm: H must be a multiple of 8 and <= 2048"); return LTR_E_INVAL; }
-  dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  if (H % 32 || H > 2048) { set_error("layernorm: H must be a multiple of 32 and <= 2048"); return LTR_E_INVAL; }
+  dim3 grid((M + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK));
   const bool split = wdtype == LTR_W_F16;
-  const int maxv = (H + 511) / 512;
+  const int maxv = (H + 255) / 256;
 #define LN_LAUNCH(SP, MV) layernorm_kernel<SP, MV><<<grid, 256, 0, s>>>(x, gamma, beta, M, H, out_f32, out_op.hi, out_op.lo)
-  if (split) {
-    if (maxv <= 1) LN_LAUNCH(true, 1); else if (maxv == 2) LN_LAUNCH(true, 2); else LN_LAUNCH(true, 4);
-  } else {
-    if (maxv <= 1) LN_LAUNCH(false, 1); else if (maxv == 2) LN_LAUNCH(false, 2); else LN_LAUNCH(false, 4);
-  }
+#define LN_PICK(SP) \
+  if (maxv <= 1) LN_LAUNCH(SP, 1); else if (maxv == 2) LN_LAUNCH(SP, 2); else if (maxv == 3) LN_LAUNCH(SP, 3); \
+  else if (maxv == 4) LN_LAUNCH(SP, 4); else LN_LAUNCH(SP, 8)
+  if (split) { LN_PICK(true); } else { LN_PICK(false); }
+#undef LN_PICK
 #undef LN_LAUNCH
   LTR_LAUNCH_CHECK();
   return LTR_OK;
@@ -234,13 +242,13 @@ int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_re
   return LTR_OK;
 }
 
-int launch_to_operand(int wdtype, const float* x, int64_t n, AOp out, hipStream_t s) {
-  if (n == 0) return LTR_OK;
-  if (n % 8) { set_error("to_operand: element count must be a multiple of 8"); return LTR_E_INVAL; }
-  int64_t n8 = n / 8;
+int launch_to_operand(int wdtype, const float* x, int M, int H, AOp out, hipStream_t s) {
+  if (M == 0) return LTR_OK;
+  if (H % 32) { set_error("to_operand: H must be a multiple of 32"); return LTR_E_INVAL; }
+  int64_t n8 = (int64_t)M * H / 8;
   int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 256 * 8);
-  if (wdtype == LTR_W_F16) to_operand_kernel<true><<<blocks, 256, 0, s>>>(x, n8, out.hi, out.lo);
-  else to_operand_kernel<false><<<blocks, 256, 0, s>>>(x, n8, out.hi, out.lo);
+  if (wdtype == LTR_W_F16) to_operand_kernel<true><<<blocks, 256, 0, s>>>(x, M, H / 8, out.hi, out.lo);
+  else to_operand_kernel<false><<<blocks, 256, 0, s>>>(x, M, H / 8, out.hi, out.lo);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
