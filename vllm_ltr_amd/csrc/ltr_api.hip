@@ -72,7 +72,7 @@ struct Workspace {
   AOp a;           // operand [Tc, H]  LN out / attention out / (De!=H: token rows)
   AOp qkv;         // [Tc, 3H]: f32 (F32 mode) or fp16 hi|lo planes written by the QKV GEMM epilogue
   AOp f;           // operand [Tc, F]  ReLU(fc1)
-  int32_t* blk;    // attention work list: int32 [Nc + 2] prefix + int2 [Tc / 32 + Nc] block descriptors
+  int32_t* blk;    // attention work list: int32 [Nc + 4] prefix + int4 [Tc / 64 + Nc + 1] block descriptors
   size_t bytes;
 };
 
@@ -87,7 +87,7 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base) {
   char* a = (char*)take(Tc * H * esz);
   char* qkv = (char*)take(Tc * 3 * H * esz);
   char* f = (char*)take(Tc * F * esz);
-  ws.blk = (int32_t*)take((Nc + 2) * 4 + (Tc / 32 + Nc + 1) * 8);
+  ws.blk = (int32_t*)take((Nc + 4) * 4 + (Tc / 64 + Nc + 1) * 16);
   if (d.weight_dtype == LTR_W_F16) {
     ws.a = AOp{a, a ? a + Tc * H * 2 : nullptr};
     ws.f = AOp{f, f ? f + Tc * F * 2 : nullptr};

@@ -35,12 +35,13 @@ constexpr int D = 64;      // head size (OPT-125m/350m: 768/12 = 1024/16 = 64)
 constexpr float NEG = -1.0e30f;
 
 // Work list of the attention launch: blk_start[i] = sum_{j<i} ceil(L_j / qb) for i in [0, n_req]
-// and, per query block b, blk_desc[b] = (request, first query of the block).  The attention
-// kernels read ONE descriptor instead of binary-searching the prefix table (a chain of ~log2 N
-// dependent loads per workgroup, which dominated the run time for short prompts).
+// and, per query block b, blk_desc[b] = (request, first query of the block, first token row of the
+// request in this chunk, request length).  The attention kernels read ONE 16-byte descriptor instead
+// of binary-searching the prefix table and then chasing cu_seqlens (every dependent global load
+// costs a workgroup of a short prompt ~1.5 us of its ~20 us life).
 __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __restrict__ cu, int n_req, int qb,
                                                            int32_t* __restrict__ blk_start,
-                                                           int2* __restrict__ blk_desc) {
+                                                           int4* __restrict__ blk_desc) {
   __shared__ int s_w[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,7 +49,8 @@ __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __rest
   __syncthreads();
   for (int base = 0; base < n_req; base += 1024) {
     int i = base + tid;
-    const int nb = (i < n_req) ? (cu[i + 1] - cu[i] + qb - 1) / qb : 0;
+    const int c0 = (i < n_req) ? cu[i] : 0, len = (i < n_req) ? cu[i + 1] - c0 : 0;
+    const int nb = (len + qb - 1) / qb;
     int v = nb;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
@@ -59,7 +61,8 @@ __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __rest
     v += off;
     if (i < n_req) {
       blk_start[i + 1] = v;
-      for (int k = 0; k < nb; ++k) blk_desc[v - nb + k] = make_int2(i, k * qb);
+      const int t0 = c0 - cu[0];
+      for (int k = 0; k < nb; ++k) blk_desc[v - nb + k] = make_int4(i, k * qb, t0, len);
     }
     __syncthreads();
     if (tid == 1023) carry = v;
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __rest
 template <bool SPLIT>
 __global__ void __launch_bounds__(64) attn_f32_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                       const int32_t* __restrict__ blk_start,
-                                                      const int2* __restrict__ blk_desc, int n_req, int H,
+                                                      const int4* __restrict__ blk_desc, int n_req, int H,
                                                       float scale_log2e, void* out_hi, void* out_lo) {
   __shared__ __attribute__((aligned(16))) float s_k[KT * D];
   __shared__ __attribute__((aligned(16))) float s_v[KT * D];
@@ -78,11 +81,10 @@ __global__ void __launch_bounds__(64) attn_f32_kernel(const float* __restrict__ 
   if (b >= blk_start[n_req]) return;
   const int head = blockIdx.y;
   const int lane = threadIdx.x;
-  const int2 desc = blk_desc[b];
-  const int r = desc.x;
+  const int4 desc = blk_desc[b];
   const int q0 = desc.y;
-  const int t0 = cu[r] - cu[0];
-  const int L = cu[r + 1] - cu[r];
+  const int t0 = desc.z;
+  const int L = desc.w;
   const int qi = q0 + lane;
   const bool valid = qi < L;
   const size_t ld = (size_t)3 * H;
@@ -200,7 +202,7 @@ __device__ __forceinline__ int k_off(int row, int c) { return row * D + ((c ^ ((
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
-    const int32_t* __restrict__ blk_start, const int2* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
+    const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
     __half* __restrict__ out_hi, __half* __restrict__ out_lo) {
   __shared__ __attribute__((aligned(16))) __half smem[NSTAGE * ATT_STAGE];   // 48 KiB ring, tiles it+1 and it+2 in flight
   constexpr int QBLK = 32 * NW;
@@ -211,11 +213,10 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int2 desc = blk_desc[b];
-  const int r = desc.x;
+  const int4 desc = blk_desc[b];
   const int qblk0 = desc.y;
-  const int t0 = cu[r] - cu[0];
-  const int L = cu[r + 1] - cu[r];
+  const int t0 = desc.z;
+  const int L = desc.w;
   const int q0 = qblk0 + wave * 32;
   const bool wave_active = q0 < L;
   const size_t ld = (size_t)3 * H;
@@ -338,12 +339,16 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
       }
     }
   }
+  // ---- output.  Lane (lq, lh) holds 4 consecutive d of query lq per (dt, j): stored directly that
+  // is 32 rows x 16 B per instruction (every 128-B line written in eight pieces).  Transpose through
+  // the (now idle) ring instead: per wave a [32 queries][64 d] tile per fp16 plane, row pitch 136 B
+  // (conflict-free 8-byte accesses), read back so that 16 lanes cover one 128-B row.
+  __syncthreads();                                      // every wave is done with the last K/V tile
   if (!wave_active) return;
   l += __shfl_xor(l, 32, 64);
-  const int qi = q0 + lq;
-  if (qi >= L) return;
   const float inv = 1.f / l;
-  const size_t ob = (size_t)(t0 + qi) * H + head * D;
+  constexpr int OPITCH = 136;                           // bytes
+  char* s_o = reinterpret_cast<char*>(smem) + wave * (2 * 32 * OPITCH);
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
@@ -352,8 +357,22 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) split_f16(o[dt][4 * j + i] * inv, hh[i], ll[i]);
       const int d = dt * 32 + 8 * j + 4 * lh;
-      *reinterpret_cast<uint2*>(out_hi + ob + d) = *reinterpret_cast<const uint2*>(hh);
-      *reinterpret_cast<uint2*>(out_lo + ob + d) = *reinterpret_cast<const uint2*>(ll);
+      *reinterpret_cast<uint2*>(s_o + lq * OPITCH + d * 2) = *reinterpret_cast<const uint2*>(hh);
+      *reinterpret_cast<uint2*>(s_o + 32 * OPITCH + lq * OPITCH + d * 2) = *reinterpret_cast<const uint2*>(ll);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int orow = lane >> 4, opiece = lane & 15;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = p * 4 + orow;
+    const uint2 vh = *reinterpret_cast<const uint2*>(s_o + row * OPITCH + opiece * 8);
+    const uint2 vl = *reinterpret_cast<const uint2*>(s_o + 32 * OPITCH + row * OPITCH + opiece * 8);
+    if (q0 + row < L) {
+      const size_t ob = (size_t)(t0 + q0 + row) * H + head * D + opiece * 4;
+      *reinterpret_cast<uint2*>(out_hi + ob) = vh;
+      *reinterpret_cast<uint2*>(out_lo + ob) = vl;
     }
   }
 }
@@ -365,8 +384,8 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
   if (n_req == 0 || T == 0) return LTR_OK;
   if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
   const float scale_log2e = 0.125f * 1.4426950408889634f;   // d^-0.5 (opt.py:73) * log2(e)
-  // scratch layout: int32 blk_start[n_req + 1] (padded to 8 B) | int2 blk_desc[max blocks]
-  int2* blk_desc = reinterpret_cast<int2*>(blk_start + ((n_req + 1 + 1) & ~1));
+  // scratch layout: int32 blk_start[n_req + 1] (padded to 16 B) | int4 blk_desc[max blocks]
+  int4* blk_desc = reinterpret_cast<int4*>(blk_start + ((n_req + 1 + 3) & ~3));
   if (wdtype == LTR_W_F16) {
     constexpr int NW = 4;
     attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start, blk_desc);
