@@ -38,6 +38,9 @@ static int g_pad = 0;
 #ifndef PROBE_NOMFMA
 #define PROBE_NOMFMA 0
 #endif
+#ifndef PROBE_M16
+#define PROBE_M16 0
+#endif
 #ifndef PROBE_NOEPI
 #define PROBE_NOEPI 0
 #endif   // extra rows in the leading dimension of K-blocked activation buffers
@@ -156,6 +159,12 @@ __global__ void __launch_bounds__(64 * WM * WN, WPS) lab_kernel(const __half* __
 #pragma unroll
   for (int s = 0; s < LA; ++s)
     if (s < nslab) issue(s);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc16[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   f16x8 pah[2], pal[2], pbw[2];
   if (PROBE_REGS) {   // fragments of slab 0, loaded once and reused for every k-step (perf probe, wrong results)
     wait_vmcnt<0>();
@@ -174,6 +183,14 @@ __global__ void __launch_bounds__(64 * WM * WN, WPS) lab_kernel(const __half* __
     if (!PROBE_DMA_ONCE && s + LA < nslab) issue(s + LA);
     const __half* st = smem + (s % ST) * STAGE;
     if (PROBE_NOMFMA) continue;
+    if (PROBE_M16) {   // power probe: same FLOPs per slab on v_mfma_f32_16x16x32_f16 (register operands, wrong results)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16((s & 1) ? pah[i & 1] : pal[i & 1], pbw[j & 1], acc16[i][j], 0, 0, 0);
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       const __half* s_ahi = st + q * SUB;
@@ -223,6 +240,12 @@ __global__ void __launch_bounds__(64 * WM * WN, WPS) lab_kernel(const __half* __
 
   if (PROBE_NOEPI) {
     float t = 0.f;
+    if (PROBE_M16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += acc16[i][j][0] + acc16[i][j][1] + acc16[i][j][2] + acc16[i][j][3];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

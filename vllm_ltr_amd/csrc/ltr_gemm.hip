@@ -13,7 +13,8 @@
 //    f32 MFMA.
 //  * F32 - exact f32 MFMA (v_mfma_f32_32x32x2_f32) for f32 checkpoints / cross-checks.
 //
-// Tiling: each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs); the
+// Tiling: each wave owns a 64x64 sub-tile = 4x4 MFMA 16x16 accumulators (64 acc VGPRs;
+// v_mfma_f32_16x16x32_f16, the more power-efficient form - see the main loop); the
 // F16 kernel uses a 128 (M) x 256 (N) tile with 8 waves (activations cost 4 B/elem as hi+lo,
 // weights 2, so the tile is wider in N), the F32 kernel 128x128 with 4 waves.  LDS layouts are chosen per
 // instruction so the fragment reads are conflict-free (see lds_off_* below).  blockIdx is
@@ -27,6 +28,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128;
 constexpr int NXCD = 8;
@@ -114,8 +116,19 @@ constexpr int W_PLANE = BN16 * BK16;              // 16 KiB
 constexpr int STAGE = 2 * A_PLANE + W_PLANE;      // a_hi | a_lo | w = 32 KiB
 constexpr int CLD = 68;                           // f32 row stride of the epilogue strip
 constexpr int CROWS = 16;                         // rows per epilogue strip
+#ifndef LTR_MFMA16
+#define LTR_MFMA16 1
+#endif
+// chunk swizzle of tile row `row` (a function of (row >> 2) & 3), chosen per fragment shape so that the
+// 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct 16-B slots of a 256-B bank row:
+//   32x32x16 fragments (lane: row l & 31, chunk 2 ks + (l >> 5)):  q
+//   16x16x32 fragments (lane: row l & 15, chunk l >> 4):           (4 - q) & 3
+__device__ __forceinline__ int swz(int row) {
+  const int q = (row >> 2) & 3;
+  return LTR_MFMA16 ? ((4 - q) & 3) : q;
+}
 __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
-  return row * BK16 + ((kc ^ ((row >> 2) & 3)) << 3);
+  return row * BK16 + ((kc ^ swz(row)) << 3);
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -146,7 +159,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
   const __half *ga, *gl, *gw[2];
   {
     const int row = wave * 16 + (lane >> 2);
-    const int c_log = (lane & 3) ^ ((row >> 2) & 3);
+    const int c_log = (lane & 3) ^ swz(row);
     // rows past M/N: any valid row, masked later.  Row-major: row pitch K; slab-major: row pitch 32, slab pitch M*32
     const size_t aoff = (size_t)min(m0 + row, M - 1) * (ep.a_slab ? BK16 : K) + c_log * 8;
     ga = a_hi + aoff;
@@ -154,7 +167,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int wrow = wave * 32 + i * 16 + (lane >> 2);
-      const int wc_log = (lane & 3) ^ ((wrow >> 2) & 3);
+      const int wc_log = (lane & 3) ^ swz(wrow);
       gw[i] = w + (size_t)min(n0 + wrow, N - 1) * BK16 + wc_log * 8;   // slab-major weight image
     }
   }
@@ -170,6 +183,18 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
                                        (lds_void*)(base + 2 * A_PLANE + (wave * 32 + i * 16) * BK16), 16, 0, 0);
   };
 
+#if LTR_MFMA16
+  // v_mfma_f32_16x16x32_f16: one instruction covers the whole 32-wide K-slab of a 16x16 block.  It
+  // moves half as many accumulator bytes per FLOP through the register file as the 32x32x16 form
+  // and, under the package power cap that bounds this kernel, sustains 15 % more FLOP/s
+  // (register-fed MFMA stream, real data: 121 vs 142 ms per bench step).
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fk = lane >> 4;
+#else
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -177,8 +202,8 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int frow = lane & 31, fk = lane >> 5;
+#endif
   const int nk = K / BK16;
 #ifdef LTR_GEMM_TIMELINE
   unsigned long long tl_dma = 0, tl_bar = 0;
@@ -201,6 +226,26 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     const __half* s_ahi = smem + (kt & 1) * STAGE;
     const __half* s_alo = s_ahi + A_PLANE;
     const __half* s_w = s_ahi + 2 * A_PLANE;
+#if LTR_MFMA16
+    {
+      f16x8 ah[4], al[4], bw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wr * 64 + i * 16 + frow;
+        ah[i] = *reinterpret_cast<const f16x8*>(s_ahi + lds_off_h(row, fk));
+        al[i] = *reinterpret_cast<const f16x8*>(s_alo + lds_off_h(row, fk));
+        const int col = wc * 64 + i * 16 + frow;
+        bw[i] = *reinterpret_cast<const f16x8*>(s_w + lds_off_h(col, fk));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 2 + fk;
@@ -221,6 +266,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
         }
     }
+#endif
   }
 
 #ifdef LTR_GEMM_TIMELINE
@@ -233,7 +279,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
   // s_waitcnt between the writes and the transposed reads is all the synchronisation needed.
   // Read-back: a lane owns 8 consecutive columns -> 16-B stores for f32 and for each fp16 plane.
   float* s_c = reinterpret_cast<float*>(smem) + wave * CROWS * CLD;
+#if !LTR_MFMA16
   const int lq = lane & 31, lh = lane >> 5;
+#endif
   const int erow = lane >> 3, ecol = (lane & 7) * 8;
   const int ccol = n0 + wc * 64 + ecol;
   float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
@@ -245,11 +293,19 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     const int i = st >> 1, half = st & 1;
+#if LTR_MFMA16
+    // 16x16 C layout: col = lane & 15, row = 4 * (lane >> 4) + e; strip st = the wave's 16-row block st
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_c[(4 * (lane >> 4) + e) * CLD + j * 16 + (lane & 15)] = acc[st][j][e];
+#else
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 8; ++r)   // register 8*half + r -> strip row (r & 3) + 8 * (r >> 2) + 4 * lh
         s_c[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + j * 32 + lq] = acc[i][j][8 * half + r];
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (ccol < N) {
