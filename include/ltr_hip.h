@@ -239,6 +239,27 @@ int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int3
                       int32_t* n_selected_out, uint8_t* ran_out, int32_t* granted_out,
                       void* stream);
 
+/* Second half of SURVEY.md 8f-1: which requests Scheduler.reserve_free_blocks
+ * (scheduler.py:1376-1452) evicts when the selection does not fit the free KV blocks, as one
+ * reversed prefix sum over the ranked order (perm[0 .. n_selected) = the selection, i.e.
+ * `pinned_requests`; the rest = `priority_requests`):
+ *   state u8 [N]: 0 waiting, 1 has RUNNING sequences, 2 has SWAPPED sequences
+ *   phys / logical / nrun / nswap int32 [N]: len(_get_physical_blocks), len(logical_token_blocks),
+ *     num_seqs(RUNNING), num_seqs(SWAPPED), all indexed by request
+ *   n_selected int32 [1] (device; e.g. ltr_budget_prefix's n_selected_out)
+ *   new_seqs NULL:   need = need_in  (num_blocks_needed - free GPU blocks + watermark, :1384-1388)
+ *   new_seqs int32 [N]: the kernel accumulates gpu_block_required over the selection like
+ *     :1137-1211 (running +new_seqs, swapped +phys+nswap, waiting +logical), writes it to
+ *     blocks_required_out (nullable) and uses need = required - need_in, need_in = free - watermark
+ *   action_out u8 [N]: 0 keep, 1 unselected running request swapped out (:1400-1420),
+ *     2 selected running request put back and preempted, 3 selected swapped / waiting request put
+ *     back (:1422-1447);  n_exec_out int32 [1] = selected requests that still execute. */
+int ltr_reserve_select(const int32_t* perm, const int32_t* n_selected, const uint8_t* state,
+                       const int32_t* phys, const int32_t* logical, const int32_t* nrun,
+                       const int32_t* nswap, const int32_t* new_seqs, int32_t N, int64_t need_in,
+                       uint8_t* action_out, int32_t* n_exec_out, int32_t* blocks_required_out,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

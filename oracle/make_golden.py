@@ -151,13 +151,14 @@ class _StubAux:
             sg.set_aux_model_score(self.table[sg.request_id])
 
 
-def _mk_scheduler(schedule_type, max_tokens, max_seqs, blocks=4096, block_size=16):
+def _mk_scheduler(schedule_type, max_tokens, max_seqs, blocks=4096, block_size=16, cpu_blocks=None):
     from vllm.config import CacheConfig, SchedulerConfig
     from vllm.core.scheduler import Scheduler
     sc = SchedulerConfig(max_tokens, max_seqs, 2048, enable_chunked_prefill=True,
                          schedule_type=schedule_type)
     cc = CacheConfig(block_size, 1.0, 1, "auto")
-    cc.num_gpu_blocks = cc.num_cpu_blocks = blocks
+    cc.num_gpu_blocks = blocks
+    cc.num_cpu_blocks = blocks if cpu_blocks is None else cpu_blocks
     return Scheduler(sc, cc, None)
 
 
@@ -304,6 +305,80 @@ def steps_fixture():
     np.savez_compressed(os.path.join(GOLD, "rank_steps.npz"), **runs_out)
 
 
+def reserve_fixture():
+    """Calls of the reference's Scheduler.reserve_free_blocks (scheduler.py:1376-1452) recorded
+    inside full schedule() runs under KV-block pressure: inputs as the vectorised form sees them
+    (rank order, selected prefix, per-request block counts / states, blocks to free) and the
+    requests it evicted (unselected running requests from the low-priority end, then selected
+    requests put back from the end of the selection)."""
+    from vllm.sequence import Logprob, SequenceStatus
+    out = {}
+    ncase = 0
+    for fi, (n, blocks, max_seqs, max_tokens, steps, lo, hi) in enumerate(
+            [(40, 40, 8, 128, 40, 20, 90), (120, 96, 16, 256, 60, 10, 140), (64, 24, 6, 96, 50, 30, 60)]):
+        rs = np.random.RandomState(300 + fi)
+        s = _mk_scheduler("opt-xxx-starv6-period3", max_tokens, max_seqs, blocks=blocks, cpu_blocks=8192)
+        sc = rs.standard_normal(n).astype(np.float16).astype(np.float32)
+        ids = [str(i) for i in range(n)]
+        s.aux_model = _StubAux({r: float(x) for r, x in zip(ids, sc)})
+        sgs = [_mk_sg(r, int(rs.randint(lo, hi))) for r in ids]
+        arrive_at = np.sort(rs.randint(0, steps // 2, n))
+        calls = []
+        inner = s.reserve_free_blocks
+
+        def spy(num_blocks_needed, pinned, priority, remaining_running, final_budget):
+            bm = s.block_manager
+            order = [g.request_id for g in pinned] + [g.request_id for g in priority]
+            rec = dict(perm=np.array([int(r) for r in order], np.int32), n_selected=len(pinned),
+                       need=int(num_blocks_needed - bm.gpu_allocator.get_num_free_blocks() + bm.watermark_blocks),
+                       state=np.zeros(n, np.uint8), phys=np.zeros(n, np.int32), logical=np.zeros(n, np.int32),
+                       nrun=np.zeros(n, np.int32), nswap=np.zeros(n, np.int32))
+            for g in list(pinned) + list(priority):
+                i = int(g.request_id)
+                nr, nsw = g.num_seqs(status=SequenceStatus.RUNNING), g.num_seqs(status=SequenceStatus.SWAPPED)
+                rec["state"][i] = 1 if nr else (2 if nsw else 0)
+                rec["nrun"][i], rec["nswap"][i] = nr, nsw
+                rec["logical"][i] = len(g.get_seqs()[0].logical_token_blocks)
+                if nr or nsw:
+                    rec["phys"][i] = len(bm._get_physical_blocks(g))
+            res = inner(num_blocks_needed, pinned, priority, remaining_running, final_budget)
+            _, exe, preempted, swapped_out = res[0], res[1], res[2], res[3]
+            act = np.zeros(n, np.uint8)
+            pinned_ids = {g.request_id for g in pinned}
+            exe_ids = {g.request_id for g in exe}
+            for g in list(preempted) + list(swapped_out):
+                act[int(g.request_id)] = 2 if g.request_id in pinned_ids else 1
+            for r in pinned_ids - exe_ids:
+                if act[int(r)] == 0:
+                    act[int(r)] = 3
+            rec["action"] = act
+            rec["n_exec"] = len(exe)
+            calls.append(rec)
+            return res
+        s.reserve_free_blocks = spy
+        for step in range(steps):
+            for i in np.nonzero(arrive_at == step)[0]:
+                s.add_seq_group(sgs[i])
+            metas, o = s.schedule()
+            for x, meta in zip(o.scheduled_seq_groups, metas):
+                x.seq_group.update_num_computed_tokens(meta.token_chunk_size)
+                if not x.seq_group.is_prefill():
+                    for seq in x.seq_group.get_seqs():
+                        seq.append_token_id(1, {1: Logprob(0.0)})
+        pressured = [c for c in calls if c["need"] > 0]
+        keep = pressured[:24] + [c for c in calls if c["need"] <= 0][:4]
+        print(f"reserve case {fi}: {len(calls)} calls, {len(pressured)} under pressure, "
+              f"actions {[int((c['action'] == k).sum()) for k in (1, 2, 3) for c in pressured[:1]]}, "
+              f"total evictions {sum(int((c['action'] > 0).sum()) for c in pressured)}")
+        for c in keep:
+            for k, v in c.items():
+                out[f"c{ncase}_{k}"] = np.asarray(v)
+            out[f"c{ncase}_n"] = np.int64(n)
+            ncase += 1
+    out["n_calls"] = np.int64(ncase)
+    np.savez_compressed(os.path.join(GOLD, "reserve_calls.npz"), **out)
+
+
 def config_fixture():
     """Round-trip the shipped predictor configs through the reference's
     PrefillPredictorConfig.from_json (config_predictor.py:136-147) and record the
@@ -369,6 +444,8 @@ if __name__ == "__main__":
         steps_fixture()
     if args.only in ("", "head"):
         ltr_head_fixture()
+    if args.only in ("", "reserve"):
+        reserve_fixture()
     if args.only in ("", "score"):
         edge = [1, 2, 4, 5, 63, 64, 65, 100, 3, 128, 17, 1, 31, 32, 33, 150]
         score_fixture("tiny_pre_ln", OPTSpec.tiny_pre_ln(), edge, 11)

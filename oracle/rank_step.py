@@ -193,3 +193,72 @@ def budget_walk(order_need_tokens, order_need_seqs, token_budget: int, max_num_s
         used_seqs += int(nseq)
         granted.append(n)
     return len(granted), granted
+
+
+# ---------------------------------------------------------------------------------------------
+# Victim selection of Scheduler.reserve_free_blocks (scheduler.py:1376-1452), next row 8f-1.
+# ---------------------------------------------------------------------------------------------
+def reserve_select(perm, n_selected, state, phys, logical, nrun, nswap, need):
+    """Which requests reserve_free_blocks evicts, restated on arrays.
+
+    perm        request indices in rank order; perm[:n_selected] is the budget walk's selection
+                (``pinned_requests``), the rest ``priority_requests``
+    state       per request: 0 waiting, 1 has RUNNING seqs, 2 has SWAPPED seqs
+    phys/logical/nrun/nswap   len(_get_physical_blocks), len(logical_token_blocks),
+                num_seqs(RUNNING), num_seqs(SWAPPED) per request
+    need        num_blocks_needed - free GPU blocks + watermark (:1384-1388)
+
+    Returns (action uint8 per request, n_exec): action 1 = unselected running request swapped out
+    (:1400-1420, walked from the lowest priority), 2 = selected running request put back and
+    preempted, 3 = selected swapped / waiting request put back (:1422-1447); n_exec = selected
+    requests that still execute.
+    """
+    n = len(state)
+    action = np.zeros(n, np.uint8)
+    n_exec = int(n_selected)
+    if need <= 0:
+        return action, n_exec
+    for i in reversed(list(perm[n_selected:])):          # :1400 reversed(priority_requests)
+        if need <= 0:
+            break
+        if state[i] == 1:                                # has RUNNING seqs
+            need -= int(phys[i])
+            action[i] = 1
+    if need > 0:                                         # :1422
+        sel = list(perm[:n_selected])
+        while need > 0 and sel:
+            i = sel.pop(-1)
+            if state[i] == 1:
+                need -= int(nrun[i]) + int(phys[i])
+                action[i] = 2
+            elif state[i] == 2:
+                need -= int(phys[i]) + int(nswap[i])
+                action[i] = 3
+            else:
+                need -= int(logical[i])
+                action[i] = 3
+        n_exec = len(sel)
+    return action, n_exec
+
+
+def reserve_select_np(perm, n_selected, state, phys, logical, nrun, nswap, need):
+    """The same as one reversed exclusive prefix sum (what the HIP kernel computes)."""
+    perm = np.asarray(perm, np.int64)
+    n = len(state)
+    action = np.zeros(n, np.uint8)
+    if need <= 0 or len(perm) == 0:
+        return action, int(n_selected)
+    pos = np.arange(len(perm))
+    st = np.asarray(state)[perm]
+    sel = pos < n_selected
+    w_unsel = np.where(st == 1, np.asarray(phys)[perm], 0)
+    w_sel = np.where(st == 1, np.asarray(nrun)[perm] + np.asarray(phys)[perm],
+                     np.where(st == 2, np.asarray(phys)[perm] + np.asarray(nswap)[perm], np.asarray(logical)[perm]))
+    w = np.where(sel, w_sel, w_unsel).astype(np.int64)
+    rev = w[::-1]
+    excl = (np.cumsum(rev) - rev)[::-1]                   # blocks freed by everything behind this position
+    hit = excl < need
+    a = np.where(sel, np.where(st == 1, 2, 3), np.where(st == 1, 1, 0))
+    a = np.where(hit, a, 0)
+    action[perm] = a.astype(np.uint8)
+    return action, int(n_selected - int((hit & sel).sum()))

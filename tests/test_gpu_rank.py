@@ -188,3 +188,85 @@ def test_budget_prefix_vs_reference_schedule(dev):
             gr = granted.cpu().numpy()
             assert gr[o[:n]].tolist() == g("granted")[step][o[:n]].tolist(), (fi, step)
             assert (ran.cpu().numpy()[o[:n]] == 1).all() and (ran.cpu().numpy()[o[n:]] == 0).all()
+
+
+def _reserve_case(z, c):
+    g = lambda k: z[f"c{c}_{k}"]
+    return (g("perm").astype(np.int32), int(g("n_selected")), g("state").astype(np.uint8), g("phys").astype(np.int32),
+            g("logical").astype(np.int32), g("nrun").astype(np.int32), g("nswap").astype(np.int32), int(g("need")),
+            g("action"), int(g("n_exec")))
+
+
+def test_reserve_select_vs_reference_calls(dev):
+    """ltr_reserve_select on the recorded calls of the reference's reserve_free_blocks
+    (tests/golden/reserve_calls.npz): same evicted set, same class per request, same n_exec."""
+    from vllm_ltr_amd.rank import reserve_select
+    z = np.load(os.path.join(GOLDEN, "reserve_calls.npz"))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    seen = {1: 0, 2: 0, 3: 0}
+    for c in range(int(z["n_calls"])):
+        perm, nsel, state, phys, logical, nrun, nswap, need, want_a, want_n = _reserve_case(z, c)
+        act, nexec, _ = reserve_select(t(perm), torch.tensor([nsel], dtype=torch.int32, device=dev), t(state), t(phys),
+                                       t(logical), t(nrun), t(nswap), need)
+        assert act.cpu().numpy().tolist() == want_a.tolist(), c
+        assert int(nexec.item()) == want_n, c
+        for k in seen:
+            seen[k] += int((want_a == k).sum())
+    assert all(v > 0 for v in seen.values()), seen       # every eviction class is exercised
+
+
+@pytest.mark.parametrize("n,frac_sel,need", [(1, 1.0, 5), (64, 0.3, 40), (1000, 0.1, 300), (8192, 0.03, 2500),
+                                             (8192, 0.03, 10**7), (5000, 0.5, 0), (3000, 0.0, 100)])
+def test_reserve_select_vs_oracle(dev, n, frac_sel, need):
+    from vllm_ltr_amd.rank import reserve_select
+    r = np.random.RandomState(n + need % 1000)
+    perm = r.permutation(n).astype(np.int32)
+    nsel = int(n * frac_sel)
+    state = r.randint(0, 3, n).astype(np.uint8)
+    phys = r.randint(1, 20, n).astype(np.int32)
+    logical = r.randint(1, 20, n).astype(np.int32)
+    nrun = (state == 1).astype(np.int32)
+    nswap = (state == 2).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    act, nexec, _ = reserve_select(t(perm), torch.tensor([nsel], dtype=torch.int32, device=dev), t(state), t(phys),
+                                   t(logical), t(nrun), t(nswap), need)
+    want_a, want_n = rs.reserve_select(perm, nsel, state, phys, logical, nrun, nswap, need)
+    assert act.cpu().numpy().tolist() == want_a.tolist()
+    assert int(nexec.item()) == want_n
+    # device-side accumulation of gpu_block_required (scheduler.py:1137-1211) + need = required - (free - watermark)
+    seqs = r.randint(1, 3, n).astype(np.int32)
+    sel = perm[:nsel]
+    required = int(np.where(state[sel] == 1, seqs[sel], np.where(state[sel] == 2, phys[sel] + nswap[sel], logical[sel])).sum())
+    free_minus_wm = required - need
+    act2, nexec2, req2 = reserve_select(t(perm), torch.tensor([nsel], dtype=torch.int32, device=dev), t(state), t(phys),
+                                        t(logical), t(nrun), t(nswap), free_minus_wm, new_seqs=t(seqs))
+    assert int(req2.item()) == required
+    assert act2.cpu().numpy().tolist() == want_a.tolist() and int(nexec2.item()) == want_n
+
+
+def test_plan_step_vs_reference_calls(dev):
+    """MI355XRanker.plan_step (budget walk + eviction choice on the device) replays the recorded
+    reserve_free_blocks calls of the reference: same swap-out list in the reference's eviction
+    order, same put-back list, same execute_pinned_requests."""
+    from types import SimpleNamespace
+    from vllm_ltr_amd.plugin import MI355XRanker
+    ranker = MI355XRanker.__new__(MI355XRanker)              # plan_step needs the device only
+    ranker.device = torch.device(dev)
+    z = np.load(os.path.join(GOLDEN, "reserve_calls.npz"))
+    for c in range(int(z["n_calls"])):
+        perm, nsel, state, phys, logical, nrun, nswap, need, want_a, want_n = _reserve_case(z, c)
+        ordered = [SimpleNamespace(request_id=int(r)) for r in perm]
+        # a budget walk that selects exactly the recorded prefix: one token each, budget = nsel
+        new_tokens = np.ones(len(perm), np.int32)
+        new_seqs = np.ones(len(perm), np.int32)
+        sel = perm[:nsel]
+        required = int(np.where(state[sel] == 1, 1, np.where(state[sel] == 2, phys[sel] + nswap[sel], logical[sel])).sum())
+        blocks = dict(state=state[perm], phys=phys[perm], logical=logical[perm], nrun=nrun[perm], nswap=nswap[perm],
+                      free=required - need, watermark=0)
+        if nsel == 0:
+            continue
+        plan = ranker.plan_step(ordered, new_tokens, new_seqs, token_budget=nsel, max_num_seqs=10**6, blocks=blocks)
+        assert [o.request_id for o in plan["selected"]] == sel.tolist()
+        assert [o.request_id for o in plan["swap_out"]] == [int(r) for r in perm[nsel:][::-1] if want_a[r] == 1], c
+        assert [o.request_id for o in plan["put_back"]] == [int(r) for r in sel[::-1] if want_a[r] in (2, 3)], c
+        assert len(plan["execute"]) == want_n, c

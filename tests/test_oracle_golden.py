@@ -176,3 +176,20 @@ def test_budget_walk_matches_reference_schedule():
             nsel, granted = rs.budget_walk(g("need_tokens")[step][o], g("need_seqs")[step][o], B, S)
             assert set(o[:nsel].tolist()) == set(np.nonzero(g("ran")[step])[0].tolist()), (fi, step)
             assert granted == g("granted")[step][o[:nsel]].tolist(), (fi, step)
+
+
+def test_reserve_select_matches_reference_calls():
+    """oracle/rank_step.reserve_select (literal) and reserve_select_np (prefix-sum form) against the
+    recorded calls of the reference's Scheduler.reserve_free_blocks under KV-block pressure."""
+    z = np.load(os.path.join(GOLDEN, "reserve_calls.npz"))
+    seen = {1: 0, 2: 0, 3: 0}
+    for c in range(int(z["n_calls"])):
+        g = lambda k: z[f"c{c}_{k}"]
+        args = (g("perm"), int(g("n_selected")), g("state"), g("phys"), g("logical"), g("nrun"), g("nswap"), int(g("need")))
+        a, ne = rs.reserve_select(*args)
+        a2, ne2 = rs.reserve_select_np(*args)
+        assert a.tolist() == g("action").tolist() and ne == int(g("n_exec")), c
+        assert a2.tolist() == a.tolist() and ne2 == ne, c
+        for k in seen:
+            seen[k] += int((g("action") == k).sum())
+    assert all(v > 0 for v in seen.values()), seen

@@ -507,4 +507,17 @@ int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int3
                               granted_out, (hipStream_t)stream);
 }
 
+int ltr_reserve_select(const int32_t* perm, const int32_t* n_selected, const uint8_t* state, const int32_t* phys,
+                       const int32_t* logical, const int32_t* nrun, const int32_t* nswap, const int32_t* new_seqs,
+                       int32_t N, int64_t need_in, uint8_t* action_out, int32_t* n_exec_out,
+                       int32_t* blocks_required_out, void* stream) {
+  if (N < 0 || !n_selected || !n_exec_out ||
+      (N > 0 && (!perm || !state || !phys || !logical || !nrun || !nswap || !action_out))) {
+    set_error("ltr_reserve_select: bad argument");
+    return LTR_E_INVAL;
+  }
+  return launch_reserve_select(perm, n_selected, state, phys, logical, nrun, nswap, new_seqs, N, need_in, action_out,
+                               n_exec_out, blocks_required_out, (hipStream_t)stream);
+}
+
 }  // extern "C"

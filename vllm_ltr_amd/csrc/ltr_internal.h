@@ -97,6 +97,10 @@ int launch_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* 
 int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int N,
                          int64_t token_budget, int64_t max_seqs, int32_t* n_sel, uint8_t* ran, int32_t* granted,
                          hipStream_t s);
+int launch_reserve_select(const int32_t* perm, const int32_t* n_sel, const uint8_t* state, const int32_t* phys,
+                          const int32_t* logical, const int32_t* nrun, const int32_t* nswap, const int32_t* new_seqs,
+                          int N, int64_t need_in, uint8_t* action, int32_t* n_exec, int32_t* blocks_required,
+                          hipStream_t s);
 
 // ---- device helpers ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -301,6 +301,89 @@ __global__ void __launch_bounds__(256) budget_mark_kernel(const int32_t* __restr
   if (granted != nullptr && k >= nsel) granted[r] = 0;
 }
 
+// Victim selection of reserve_free_blocks (scheduler.py:1376-1452) as ONE reversed exclusive prefix
+// sum over the ranked order: position k (request r = perm[k]) frees w_k blocks when evicted,
+//   unselected (k >= n_sel): w = phys[r] if r has RUNNING sequences else 0     (:1400-1420)
+//   selected   (k <  n_sel): w = nrun + phys (running) | phys + nswap (swapped) | logical (waiting)   (:1422-1447)
+// and is evicted iff the blocks freed by everything behind it are still short of `need`
+// (the reference walks from the low-priority end and stops as soon as need <= 0).
+// With new_seqs != nullptr the kernel first accumulates gpu_block_required of the selection
+// (:1137-1211: running +new_seqs, swapped +phys+nswap, waiting +logical) and need = required - need_in.
+// Single workgroup, blocked scan from the end; stops at the first block that needs no eviction.
+__global__ void __launch_bounds__(BP_THREADS) reserve_select_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ n_sel_p, const uint8_t* __restrict__ state,
+    const int32_t* __restrict__ phys, const int32_t* __restrict__ logical, const int32_t* __restrict__ nrun,
+    const int32_t* __restrict__ nswap, const int32_t* __restrict__ new_seqs, int N, long long need_in,
+    uint8_t* __restrict__ action, int32_t* __restrict__ n_exec, int32_t* __restrict__ blocks_required) {
+  __shared__ long long s_w[BP_THREADS / 64];
+  __shared__ long long carry, s_need;
+  __shared__ int s_popped;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nsel = min(*n_sel_p, N);
+  // action defaults to 0 everywhere
+  for (int k = tid; k < N; k += BP_THREADS) action[perm[k]] = 0;
+  long long req = 0;
+  if (new_seqs != nullptr) {
+    for (int k = tid; k < nsel; k += BP_THREADS) {
+      const int r = perm[k];
+      const int st = state[r];
+      req += st == 1 ? new_seqs[r] : (st == 2 ? phys[r] + nswap[r] : logical[r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) req += __shfl_xor(req, o, 64);
+    if (lane == 0) s_w[wave] = req;
+  }
+  if (tid == 0) { carry = 0; s_popped = 0; }
+  __syncthreads();
+  if (tid == 0) {
+    long long need = need_in;
+    if (new_seqs != nullptr) {
+      long long t = 0;
+      for (int w = 0; w < BP_THREADS / 64; ++w) t += s_w[w];
+      if (blocks_required) *blocks_required = (int32_t)t;
+      need = t - need_in;
+    } else if (blocks_required) {
+      *blocks_required = 0;
+    }
+    s_need = need;
+  }
+  __syncthreads();
+  const long long need = s_need;
+  if (need > 0) {
+    for (int base = 0; base < N; base += BP_THREADS) {
+      const int k = N - 1 - (base + tid);               // walk from the low-priority end
+      long long w = 0;
+      int r = 0, st = 0;
+      bool sel = false;
+      if (k >= 0) {
+        r = perm[k]; st = state[r]; sel = k < nsel;
+        if (sel) w = st == 1 ? (long long)nrun[r] + phys[r] : (st == 2 ? (long long)phys[r] + nswap[r] : (long long)logical[r]);
+        else w = st == 1 ? phys[r] : 0;
+      }
+      long long t = w;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { long long tt = __shfl_up(t, o, 64); if (lane >= o) t += tt; }
+      __syncthreads();                                   // previous round's s_w / carry reads are done
+      if (lane == 63) s_w[wave] = t;
+      __syncthreads();
+      long long off = carry;
+      for (int x = 0; x < wave; ++x) off += s_w[x];
+      t += off;
+      const long long before = t - w;                    // freed by everything behind this position
+      if (k >= 0 && before < need) {
+        if (sel) { action[r] = st == 1 ? 2 : 3; atomicAdd(&s_popped, 1); }
+        else if (st == 1) action[r] = 1;
+      }
+      __syncthreads();
+      if (tid == BP_THREADS - 1) carry = t;
+      __syncthreads();
+      if (carry >= need) break;                          // uniform
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *n_exec = nsel - s_popped;
+}
+
 }  // namespace
 
 // keys u64[n] | rank i32[n] | (bucket path) bkeys u64[n] | bidx i32[n] | slot i32[n] | bid u8[n] |
@@ -400,6 +483,16 @@ int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const i
     budget_mark_kernel<<<(N + 255) / 256, 256, 0, s>>>(perm, N, n_sel, ran, granted);
     LTR_LAUNCH_CHECK();
   }
+  return LTR_OK;
+}
+
+int launch_reserve_select(const int32_t* perm, const int32_t* n_sel, const uint8_t* state, const int32_t* phys,
+                          const int32_t* logical, const int32_t* nrun, const int32_t* nswap, const int32_t* new_seqs,
+                          int N, int64_t need_in, uint8_t* action, int32_t* n_exec, int32_t* blocks_required,
+                          hipStream_t s) {
+  reserve_select_kernel<<<1, BP_THREADS, 0, s>>>(perm, n_sel, state, phys, logical, nrun, nswap, new_seqs, N,
+                                                 (long long)need_in, action, n_exec, blocks_required);
+  LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
 

@@ -37,7 +37,7 @@ import torch
 from . import _lib
 from .config_predictor import PrefillPredictorConfig
 from .opt_spec import OPTSpec, load_hf_checkpoint
-from .rank import RankWorkspace, age_update, rank_step
+from .rank import RankWorkspace, age_update, budget_prefix, rank_step, reserve_select
 from .schedule_type import ScheduleType, parse_schedule_type
 from .scorer import HipOPTScorer
 
@@ -207,6 +207,51 @@ class MI355XRanker:
         st = dev.cpu().numpy()
         for i, r in enumerate(all_pri):
             r.pri = int(st[0, i]); r.idle = int(st[1, i]); r.runs = int(st[2, i])
+
+    # ---- front half of _general_schedule: budget walk + eviction choice -----------------------
+    def plan_step(self, ordered: Sequence, new_tokens: Sequence[int], new_seqs: Sequence[int], token_budget: int,
+                  max_num_seqs: int, blocks: Optional[dict] = None) -> dict:
+        """What ``_general_schedule`` decides between the sort and the block-table updates
+        (scheduler.py:1137-1218): the prefix of ``ordered`` the budget walk selects with the tokens
+        granted to each request, and - when ``blocks`` describes the KV-block state - the requests
+        ``reserve_free_blocks`` (:1376-1452) evicts.  Both run on the device (``ltr_budget_prefix``,
+        ``ltr_reserve_select``); one D2H copy brings the decisions back.
+
+        ordered       the ranked list (``ordered_requests``)
+        new_tokens    per element: un-chunked ``_get_num_new_tokens`` (:1878-1881)
+        new_seqs      per element: ``get_max_num_running_seqs()``
+        blocks        None, or dict(state=, phys=, logical=, nrun=, nswap=, free=, watermark=) with
+                      per-element sequences and the block manager's two scalars
+
+        Returns dict(selected=[...], granted=[...], swap_out=[...], put_back=[...], execute=[...]):
+        ``swap_out`` = unselected running requests to swap out, lowest priority first;
+        ``put_back`` = selected requests dropped from the selection, last selected first;
+        ``execute``  = ``execute_pinned_requests``."""
+        n = len(ordered)
+        if n == 0:
+            return dict(selected=[], granted=[], swap_out=[], put_back=[], execute=[])
+        dev = self.device
+        i32 = lambda a: torch.from_numpy(np.asarray(a, np.int32)).to(dev)
+        perm = torch.arange(n, dtype=torch.int32, device=dev)       # `ordered` is already in rank order
+        nt, nq = i32(new_tokens), i32(new_seqs)
+        n_sel, _, granted = budget_prefix(perm, nt, nq, token_budget, max_num_seqs, want_ran=False)
+        if blocks is None:
+            k = int(n_sel.item())
+            g = granted[:k].cpu().numpy()
+            sel = list(ordered[:k])
+            return dict(selected=sel, granted=g.tolist(), swap_out=[], put_back=[], execute=sel)
+        state = torch.from_numpy(np.asarray(blocks["state"], np.uint8)).to(dev)
+        action, n_exec, _ = reserve_select(perm, n_sel, state, i32(blocks["phys"]), i32(blocks["logical"]),
+                                           i32(blocks["nrun"]), i32(blocks["nswap"]),
+                                           int(blocks["free"]) - int(blocks["watermark"]), new_seqs=nq)
+        host = torch.cat([n_sel, n_exec, granted, action.to(torch.int32)]).cpu().numpy()
+        k, ke = int(host[0]), int(host[1])
+        g, act = host[2:2 + n], host[2 + n:]
+        sel = list(ordered[:k])
+        swap_out = [ordered[i] for i in range(n - 1, k - 1, -1) if act[i] == 1]
+        put_back = [ordered[i] for i in range(k - 1, -1, -1) if act[i] in (2, 3)]
+        return dict(selected=sel, granted=g[:k].tolist(), swap_out=swap_out, put_back=put_back,
+                    execute=sel[:ke])
 
     # ---- wiring ------------------------------------------------------------------------------
     def install(self, scheduler) -> None:

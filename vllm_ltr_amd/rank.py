@@ -93,6 +93,29 @@ def budget_prefix(perm: torch.Tensor, new_tokens: torch.Tensor, new_seqs: torch.
     return n_sel, ran, granted
 
 
+def reserve_select(perm: torch.Tensor, n_selected: torch.Tensor, state: torch.Tensor, phys: torch.Tensor,
+                   logical: torch.Tensor, nrun: torch.Tensor, nswap: torch.Tensor, need: int,
+                   new_seqs: Optional[torch.Tensor] = None):
+    """Victim selection of ``Scheduler.reserve_free_blocks`` (scheduler.py:1376-1452) over the ranked
+    order.  ``n_selected``: int32[1] device tensor (``budget_prefix``'s first result).
+    ``new_seqs`` None: ``need`` = num_blocks_needed - free GPU blocks + watermark;
+    ``new_seqs`` given: ``need`` = free GPU blocks - watermark and the blocks the selection requires
+    are accumulated on the device.  Returns (action uint8[n_req], n_exec int32[1], blocks_required int32[1])."""
+    N = perm.numel()
+    n_req = state.numel()
+    dev = perm.device
+    action = (torch.empty if n_req == N else torch.zeros)(n_req, dtype=torch.uint8, device=dev)
+    n_exec = torch.empty(1, dtype=torch.int32, device=dev)
+    req = torch.empty(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ltr_reserve_select(perm.data_ptr(), n_selected.data_ptr(), state.data_ptr(), phys.data_ptr(),
+                                      logical.data_ptr(), nrun.data_ptr(), nswap.data_ptr(),
+                                      new_seqs.data_ptr() if new_seqs is not None else None, N, int(need),
+                                      action.data_ptr(), n_exec.data_ptr(), req.data_ptr(), _stream(dev)),
+               "ltr_reserve_select")
+    return action, n_exec, req
+
+
 class DeviceQueue:
     """Device-resident ranking state of the scheduler queue: ``score``, ``pri``,
     ``idle``, ``runs`` per queued request (slot order = the order of
