@@ -138,3 +138,32 @@ def test_pack_layout():
     assert ids.dtype == np.int64 and cu.dtype == np.int32
     ids, cu = HipOPTScorer.pack([])
     assert ids.shape == (0,) and cu.tolist() == [0]
+
+
+def test_input_stager_and_token_cache():
+    """Host input pipeline: ids are produced once per request and cached; packing
+    equals HipOPTScorer.pack; buffers grow and are reused."""
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.host_pipeline import InputStager, cached_token_ids
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    calls = []
+
+    def tok(text):
+        calls.append(text)
+        return [2] + [ord(c) for c in text]
+    g = FakeSeqGroup("a", [], prompt="hello world")
+    a = cached_token_ids(g, tok, 6)
+    b = cached_token_ids(g, tok, 6)
+    assert a is b and calls == ["hello world"] and a.tolist() == [2] + [ord(c) for c in "hello"]
+    with pytest.raises(ValueError):
+        cached_token_ids(FakeSeqGroup("e", []), None, 10)
+    st = InputStager("cpu", capacity_tokens=4, capacity_requests=1)
+    r = np.random.RandomState(0)
+    for n in (1, 7, 300):
+        lists = [r.randint(0, 1000, r.randint(1, 40)).tolist() for _ in range(n)]
+        ids_d, cu_d, cu_h = st.stage([np.asarray(x, np.int64) for x in lists])
+        want_ids, want_cu = HipOPTScorer.pack(lists)
+        assert ids_d.numpy().tolist() == want_ids.tolist() and cu_d.numpy().tolist() == want_cu.tolist()
+        assert cu_h.tolist() == want_cu.tolist()
+    ids_d, cu_d, cu_h = st.stage([])
+    assert ids_d.numel() == 0 and cu_d.tolist() == [0]

@@ -36,6 +36,7 @@ import torch
 
 from . import _lib
 from .config_predictor import PrefillPredictorConfig
+from .host_pipeline import InputStager, cached_token_ids
 from .opt_spec import OPTSpec, load_hf_checkpoint
 from .rank import RankWorkspace, age_update, budget_prefix, rank_step, reserve_select
 from .schedule_type import ScheduleType, parse_schedule_type
@@ -77,6 +78,7 @@ class MI355XRanker:
         if mtype == "rank" and scorer.spec.num_labels != 1:
             raise ValueError("mtype 'rank' needs num_labels == 1 (prefill_predictor.py:35-36)")
         self._ws = RankWorkspace(self.device)
+        self._stager = InputStager(self.device)
         self.stats = dict(aux_calls=0, requests_scored=0, rank_calls=0, score_seconds=0.0, rank_seconds=0.0)
 
     # ---- construction from the reference's config objects ------------------------------
@@ -94,18 +96,10 @@ class MI355XRanker:
                    mtype=cfg.model.mtype)
 
     # ---- AUXLLM.obtain_aux_scores -------------------------------------------------------
-    def _token_ids(self, sg) -> Sequence[int]:
-        if self.tokenize is not None:
-            prompt = getattr(sg, "prompt", None)
-            if prompt is None:      # SequenceGroup.seqs_dict[first].prompt (aux_llm_engine.py:341)
-                prompt = next(iter(sg.seqs_dict.values())).prompt
-            ids = self.tokenize(prompt)
-        else:
-            ids = sg.prompt_token_ids
-        ids = ids[:self.max_length]                        # aux_llm_engine.py:365-369
-        if len(ids) == 0:
-            raise ValueError(f"request {sg.request_id}: empty prompt cannot be scored")
-        return ids
+    def add_request(self, sg) -> None:
+        """Optional arrival-time hook (where ``Scheduler.add_seq_group`` runs, scheduler.py:368-376):
+        tokenise / truncate the prompt once so the scoring call only packs cached arrays."""
+        cached_token_ids(sg, self.tokenize, self.max_length)
 
     def obtain_aux_scores(self, seq_groups) -> List[float]:
         seq_groups = list(seq_groups)
@@ -114,9 +108,10 @@ class MI355XRanker:
         t0 = time.perf_counter()
         for sg in seq_groups:
             assert sg.need_aux_model_score()               # aux_llm_engine.py:409
-        ids, cu = HipOPTScorer.pack([self._token_ids(sg) for sg in seq_groups])
-        scores = self.scorer.score(ids, cu)
-        out = [float(s) for s in scores]                   # opt.py:408 .tolist()
+        arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in seq_groups]
+        ids_dev, cu_dev, cu_host = self._stager.stage(arrays)          # pinned pack + async H2D
+        scores = self._stager.fetch_scores(self.scorer.score_device(ids_dev, cu_dev, cu_host))
+        out = scores.tolist()                              # opt.py:408 .tolist()
         for sg, s in zip(seq_groups, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
         self.stats["aux_calls"] += 1
