@@ -192,6 +192,21 @@ def main():
         b.record()
     torch.cuda.synchronize()
     rank_ms = sorted(a.elapsed_time(b) for a, b in rk)
+    # steady call with k = 256 new requests: score the first 256 of the local queue,
+    # then promote/demote + sort + budget prefix + aging over the whole queue
+    k_new = min(256, n_local)
+    cu_k = np.ascontiguousarray(cu[:k_new + 1])
+    ids_k, cu_k_d = ids_d[:int(cu_k[-1])], cu_d[:k_new + 1]
+    sk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for i, (a, b) in enumerate(sk):
+        a.record()
+        queue._score[:k_new].copy_(scorer.score_device(ids_k, cu_k_d, cu_k))
+        queue.rank(out=perm)
+        _, ran, _ = budget_prefix(perm, need_tokens, need_seqs, 2048, 256, want_granted=False)
+        queue.age(ran)
+        b.record()
+    torch.cuda.synchronize()
+    steady_k_ms = sorted(a.elapsed_time(b) for a, b in sk[2:])
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -228,6 +243,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "p50_rank_latency_ms": step_ms[len(step_ms) // 2],
             "p50_steady_rank_latency_ms": rank_ms[len(rank_ms) // 2],
+            "p50_steady_256new_latency_ms": steady_k_ms[len(steady_k_ms) // 2],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if args.weight_dtype == "f16" else "f32",
             "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths, random token ids)",
