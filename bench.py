@@ -120,13 +120,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # LTR_BENCH_ONE_DEVICE=1 + LTR_BENCH_BACKEND=gloo: dry run of the N-rank path on a 1-GPU box (test hook)
+    if os.environ.get("LTR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("LTR_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vllm_ltr_amd.distributed import gather_scores
     from vllm_ltr_amd.rank import DeviceQueue, budget_prefix
