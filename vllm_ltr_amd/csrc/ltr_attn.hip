@@ -204,7 +204,9 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
     const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
     __half* __restrict__ out_hi, __half* __restrict__ out_lo) {
-  __shared__ __attribute__((aligned(16))) __half smem[NSTAGE * ATT_STAGE];   // 48 KiB ring, tiles it+1 and it+2 in flight
+  // 48 KiB ring, tiles it+1 and it+2 in flight.  Dynamic LDS on purpose: with a static array hipcc tracks the
+  // LDS-DMA stores against every ds_read and drains vmcnt(0) in front of the first fragment read
+  extern __shared__ __attribute__((aligned(16))) __half smem[];
   constexpr int QBLK = 32 * NW;
   static_assert(NW == 4, "load map below assumes 4 waves (one 8-row group of each plane per wave)");
 
@@ -257,11 +259,17 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   // tile of look-ahead left the waves parked on vmcnt).  Counted waits: 4 loads per tile.
   issue(0, 0);
   if (ntile > 1) issue(1, TK);
+  // Pin the Q fragments here: hipcc then waits for the (older) Q loads with a counted vmcnt BEFORE the
+  // loop; left to itself it re-waits vmcnt(0) at their first use in every iteration, which also drains
+  // the look-ahead tiles.
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qh[ks]), "v"(ql[ks]));
   for (int it = 0; it < ntile; ++it) {
     const int kt = it * TK;
     if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it landed, it+1 may fly
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                    // everyone's rows landed; tile it-1 fully consumed
+    // raw barrier: __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for the look-ahead tiles too
+    __builtin_amdgcn_s_barrier();                       // everyone's rows landed; tile it-1 fully consumed
     if (it + 2 < ntile) issue((it + 2) % NSTAGE, kt + 2 * TK);
     if (!wave_active || kt > q0) continue;              // wave-uniform: past this wave's diagonal
     const __half* s_khi = smem + (it % NSTAGE) * ATT_STAGE;
@@ -391,7 +399,7 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
     attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start, blk_desc);
     LTR_LAUNCH_CHECK();
     dim3 grid(T / (32 * NW) + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
-    attn_f16s_kernel<NW><<<grid, NW * 64, 0, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
+    attn_f16s_kernel<NW><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
                                                   n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo);
   } else {
     attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start, blk_desc);
