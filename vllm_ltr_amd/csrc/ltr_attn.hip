@@ -190,14 +190,19 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // LDS stage: K hi | K lo | V hi | V lo, each [32 keys][64 d] halves (4 KiB), filled by
 // global_load_lds (lane-linear image: one wave instruction = 8 rows x 128 B).
 // K: 16-B chunk c of row r holds logical chunk c ^ ((r >> 1) & 7) (source-side swizzle) so
-// the ds_read_b128 A-fragment reads are conflict-free.  V: plain row-major; its fragments
-// (8 keys of one d column per lane) are gathered with 2-byte reads - lanes of a half-wave
-// read 32 consecutive halves of one key row, which is conflict-free - so no transposed
-// copy of V is ever written.
+// the ds_read_b128 A-fragment reads are conflict-free.  V: row-major; its fragments (8 keys of
+// one d column per lane) come out of ds_read_b64_tr_b16, the hardware transpose read, so no
+// transposed copy of V is ever written (2-byte gathers cost 64 reads + ~40 packs per tile).
 constexpr int PLANE_H = TK * D;                 // halves per plane
 constexpr int ATT_STAGE = 4 * PLANE_H;          // 16 KiB
 constexpr int NSTAGE = 3;
 __device__ __forceinline__ int k_off(int row, int c) { return row * D + ((c ^ ((row >> 1) & 7)) << 3); }
+// V: 32-B column block cb of key row r sits at block cb ^ ((r >> 1) & 1), so that the four key rows a
+// transpose read touches (two 256-B bank rows) fall on distinct banks
+__device__ __forceinline__ int v_off(int row, int d) { return row * D + ((((d >> 4) ^ ((row >> 1) & 1)) << 4) | (d & 15)); }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
@@ -242,7 +247,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   // tile loads: wave w fills rows 8w..8w+7 of each of the four planes (1 KiB each)
   const int lrow = wave * 8 + (lane >> 3);                      // key row inside the tile
   const int kc_log = (lane & 7) ^ ((lrow >> 1) & 7);            // K: swizzled source chunk
-  const int vc = lane & 7;                                      // V: linear
+  const int vc = (lane & 7) ^ (((lrow >> 1) & 1) << 1);         // V: 32-B blocks swapped on odd row pairs (v_off)
   auto issue = [&](int stage, int kt) {
     const size_t rowoff = (size_t)(t0 + min(kt + lrow, L - 1)) * ld + head * D;
     __half* base = smem + stage * ATT_STAGE + wave * 8 * D;
@@ -326,19 +331,24 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
     }
     l += psum;
     // ---- O^T += V^T P^T  (rows = d, cols = queries).  A fragment of k-step g: element e of
-    // lane-half lh is key 16g + 8(e>>2) + 4lh + (e&3) - the accumulator register order of S^T -
-    // gathered from the row-major V tile with 2-byte reads.
+    // lane-half lh is key 16g + 8(e>>2) + 4lh + (e&3) - the accumulator register order of S^T.
+    // The V tile is row-major [key][d]; ds_read_b64_tr_b16 transposes a [4 keys][16 d] block inside
+    // every 16-lane group (lane j supplies the address of key j>>2, d-chunk j&3 and receives column
+    // j of the four keys), so one read yields e = 0..3 (or 4..7) of this lane's d = dt*32 + lq.
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         f16x8 vh, vl;
-        const int vbase = (16 * g + 4 * lh) * D + dt * 32 + lq;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int off = vbase + (8 * (e >> 2) + (e & 3)) * D;
-          vh[e] = reinterpret_cast<const _Float16*>(s_vhi)[off];
-          vl[e] = reinterpret_cast<const _Float16*>(s_vlo)[off];
+        for (int hf = 0; hf < 2; ++hf) {
+          const int key = 16 * g + 8 * hf + 4 * lh + ((lane & 15) >> 2);
+          const int off = v_off(key, dt * 32 + (lane & 16) + (lane & 3) * 4);
+          const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_vhi + off));
+          const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_vlo + off));
+          const f16x4 ah = __builtin_bit_cast(f16x4, a), bl = __builtin_bit_cast(f16x4, b);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vh[4 * hf + e] = ah[e]; vl[4 * hf + e] = bl[e]; }
         }
         const f16x8 ph = g ? ph1 : ph0, pl = g ? pl1 : pl0;
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
