@@ -178,7 +178,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     {
       ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
       rc = launch_attention(m->dbg_attn_valu && wd == LTR_W_F16 ? -1 : wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads,
-                            ws.blk, ws.a, s);
+                            ws.blk, ws.a, L == 0, s);
     }
     if (rc) return rc;
     if (prune_last && L == nl - 1) {

@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
 }  // namespace
 
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
-                     int32_t* blk_start, AOp out, hipStream_t s) {
+                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s) {
   if (n_req == 0 || T == 0) return LTR_OK;
   if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
   const float scale_log2e = 0.125f * 1.4426950408889634f;   // d^-0.5 (opt.py:73) * log2(e)
@@ -406,14 +406,18 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
   int4* blk_desc = reinterpret_cast<int4*>(blk_start + ((n_req + 1 + 3) & ~3));
   if (wdtype == LTR_W_F16) {
     constexpr int NW = 4;
-    attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start, blk_desc);
-    LTR_LAUNCH_CHECK();
+    if (build_blocks) {   // the work list depends on cu_seqlens only: built once per pass, reused by every layer
+      attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start, blk_desc);
+      LTR_LAUNCH_CHECK();
+    }
     dim3 grid(T / (32 * NW) + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
     attn_f16s_kernel<NW><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
                                                   n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo);
   } else {
-    attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start, blk_desc);
-    LTR_LAUNCH_CHECK();
+    if (build_blocks) {
+      attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start, blk_desc);
+      LTR_LAUNCH_CHECK();
+    }
     dim3 grid(T / QB + n_req, n_heads);
     if (wdtype == LTR_W_F32)
       attn_f32_kernel<false><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, blk_desc, n_req, H, scale_log2e,
