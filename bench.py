@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--starv", type=int, default=200)
     ap.add_argument("--period", type=int, default=10)
+    ap.add_argument("--steady-new", type=int, default=0,
+                    help="also time the steady call with this many new requests (SURVEY 8d: 256); off by default so "
+                         "that a rocprofv3 trace of the default command holds the cold-call launches only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,10 +204,11 @@ def main():
     rank_ms = sorted(a.elapsed_time(b) for a, b in rk)
     # steady call with k = 256 new requests: score the first 256 of the local queue,
     # then promote/demote + sort + budget prefix + aging over the whole queue
-    k_new = min(256, n_local)
+    k_new = min(args.steady_new, n_local)
+    steady_k_ms = []
     cu_k = np.ascontiguousarray(cu[:k_new + 1])
     ids_k, cu_k_d = ids_d[:int(cu_k[-1])], cu_d[:k_new + 1]
-    sk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    sk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10 if k_new else 0)]
     for i, (a, b) in enumerate(sk):
         a.record()
         queue._score[:k_new].copy_(scorer.score_device(ids_k, cu_k_d, cu_k))
@@ -213,7 +217,8 @@ def main():
         queue.age(ran)
         b.record()
     torch.cuda.synchronize()
-    steady_k_ms = sorted(a.elapsed_time(b) for a, b in sk[2:])
+    if k_new:
+        steady_k_ms = sorted(a.elapsed_time(b) for a, b in sk[2:])
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -250,7 +255,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "p50_rank_latency_ms": step_ms[len(step_ms) // 2],
             "p50_steady_rank_latency_ms": rank_ms[len(rank_ms) // 2],
-            "p50_steady_256new_latency_ms": steady_k_ms[len(steady_k_ms) // 2],
+            "p50_steady_new_latency_ms": steady_k_ms[len(steady_k_ms) // 2] if steady_k_ms else None,
+            "steady_new_requests": k_new,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if args.weight_dtype == "f16" else "f32",
             "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths, random token ids)",

@@ -4,7 +4,7 @@ out=${1:-gpurun_out/queue_sweep.jsonl}
 : > $out
 for q in 256 1024 2048 4096 8192 16384 32768 65536; do
   steps=3; [ $q -ge 32768 ] && steps=2
-  python bench.py --steps $steps --warmup 1 --queue $q --no-cpu-baseline >> $out
+  python bench.py --steps $steps --warmup 1 --queue $q --no-cpu-baseline --steady-new 256 >> $out
 done
 python - "$out" <<'PY'
 import json, sys
