@@ -270,3 +270,26 @@ def test_plan_step_vs_reference_calls(dev):
         assert [o.request_id for o in plan["swap_out"]] == [int(r) for r in perm[nsel:][::-1] if want_a[r] == 1], c
         assert [o.request_id for o in plan["put_back"]] == [int(r) for r in sel[::-1] if want_a[r] in (2, 3)], c
         assert len(plan["execute"]) == want_n, c
+
+
+def test_scan_kernels_edge_inputs(dev):
+    """Empty queues and error codes of the scan kernels through the C ABI."""
+    from vllm_ltr_amd import _lib
+    from vllm_ltr_amd.rank import budget_prefix, reserve_select
+    e32 = torch.zeros(0, dtype=torch.int32, device=dev)
+    e8 = torch.zeros(0, dtype=torch.uint8, device=dev)
+    nsel, ran, granted = budget_prefix(e32, e32, e32, 100, 10)
+    assert int(nsel.item()) == 0 and ran.numel() == 0 and granted.numel() == 0
+    act, nexec, req = reserve_select(e32, nsel, e8, e32, e32, e32, e32, 5)
+    assert act.numel() == 0 and int(nexec.item()) == 0
+    lib = _lib.load()
+    assert lib.ltr_reserve_select(None, None, None, None, None, None, None, None, 4, 1, None, None, None, None) == -22   # LTR_E_INVAL
+    assert b"ltr_reserve_select" in lib.ltr_last_error()
+    # nothing selected, pressure: only unselected running requests can be evicted
+    n = 50
+    perm = torch.arange(n, dtype=torch.int32, device=dev)
+    state = torch.ones(n, dtype=torch.uint8, device=dev)
+    ones = torch.ones(n, dtype=torch.int32, device=dev)
+    act, nexec, _ = reserve_select(perm, torch.zeros(1, dtype=torch.int32, device=dev), state, 2 * ones, ones, ones, 0 * ones, 7)
+    a = act.cpu().numpy()
+    assert a[-4:].tolist() == [1, 1, 1, 1] and a[:-4].sum() == 0 and int(nexec.item()) == 0   # ceil(7 / 2) victims from the end
