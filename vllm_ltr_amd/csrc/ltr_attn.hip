@@ -11,7 +11,7 @@
 // F16 ("split") mode - attn_f16s_kernel, the production kernel.  q, k, v arrive as fp16
 // hi|lo planes written by the QKV GEMM epilogue.  A workgroup is 4 waves = 128 consecutive
 // queries of one (request, head), 32 per wave; K/V tiles of 32 keys stream HBM -> LDS with
-// global_load_lds (two stages, one barrier per tile).  Per 32x32 (key, query) block:
+// global_load_lds (ring of three stages, one raw barrier per tile).  Per 32x32 (key, query) block:
 //   S^T = K Q^T      on v_mfma_f32_32x32x16_f16, 3 passes (kh*qh + kh*ql + kl*qh)
 //   online softmax   lane-local: with the S^T layout a lane holds 16 keys of ONE query
 //                    (col = lane & 31), so row max / sum are 15 in-lane ops + one
@@ -19,8 +19,9 @@
 //   O^T += V^T P^T   3 passes (vh*ph + vh*pl + vl*ph); the S^T accumulator registers,
 //                    converted to fp16, ARE the B operand (the key <-> k-slot assignment
 //                    of an MFMA is arbitrary as long as A and B agree, so the V^T fragment
-//                    is gathered from the row-major V tile in that key order: no
-//                    cross-lane shuffle and no transposed copy of V).
+//                    is read from the row-major V tile in that key order with the
+//                    transpose read ds_read_b64_tr_b16: no cross-lane shuffle and no
+//                    transposed copy of V).
 // The dropped lo*lo terms are ~2^-22 relative: f32-grade, as in the GEMMs.
 //
 // F32 mode - attn_f32_kernel: exact f32 VALU flash kernel, one query row per lane.

@@ -7,7 +7,7 @@
 // Two arithmetic modes, selected by the checkpoint dtype:
 //  * F16 ("split") - the production path.  The checkpoint is fp16 (train/trainer.py:215),
 //    so W is exact in fp16.  Activations are carried as two fp16 planes a = hi + lo;
-//    acc += hi*W; acc += lo*W on v_mfma_f32_32x32x16_f16 with f32 accumulation.  That keeps
+//    acc += lo*W; acc += hi*W on v_mfma_f32_16x16x32_f16 with f32 accumulation.  That keeps
 //    ~22 significant bits of the f32 activation (score error vs the f32 CPU oracle ~4e-6,
 //    where plain fp16 activations give 2e-3), at 2 MFMA passes instead of the 16x slower
 //    f32 MFMA.
@@ -103,10 +103,10 @@ __device__ __forceinline__ void store_tile(const Epilogue& e, const f32x16& acc,
 // swizzle is applied on the SOURCE side: the lane that fills physical 16-B chunk c of row r
 // fetches logical chunk c ^ ((r >> 2) & 3), and fragment reads apply the same XOR.  With it
 // a ds_read_b128 lane group (rows {0-3,12-15,20-27} / ...) touches 16 distinct 16-B slots of
-// the 256-B bank row -> conflict-free.  Two LDS stages (2 x 24 KiB): slab k+1 streams in
+// the 256-B bank row -> conflict-free.  Two LDS stages (2 x 32 KiB): slab k+1 streams in
 // while slab k is multiplied; one barrier per slab.  All LDS lives in ONE array (a second
 // __shared__ object makes hipcc drain vmcnt before every ds_read of the pipeline).
-// Epilogue: accumulators -> LDS (per-wave 32x64 f32 strips) -> 16 B per lane coalesced
+// Epilogue: accumulators -> LDS (per-wave 16x64 f32 strips) -> 16 B per lane coalesced
 // global stores with bias / ReLU / residual / fp16 hi|lo split fused.
 // ------------------------------------------------------------------------------------
 constexpr int BK16 = 32;
