@@ -271,3 +271,26 @@ def test_plugin_tpt_and_xpt_orders(dev):
         m.output_len = g.output_len
     want = rs.xpt_order(mirror, key, value, lambda q: q.output_len)
     assert [g.request_id for g in got] == [m.request_id for m in want]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["tiny_pre_ln", "tiny_post_ln"])
+def test_outlier_activations(dev, variant):
+    """Trained OPT checkpoints carry a few 'massive activation' channels; the hi|lo split must keep its
+    f32-grade relative accuracy when the residual stream spans several orders of magnitude (and stay
+    finite: hi is an fp16).  Weights 5x the init scale plus two embedding channels at ~60x."""
+    spec = OPTSpec.tiny_pre_ln() if variant == "tiny_pre_ln" else OPTSpec.tiny_post_ln()
+    ckpt = seeded_checkpoint(spec, 31, std=0.1, qk_std=0.15)
+    r = np.random.RandomState(5)
+    for name in ("model.decoder.embed_tokens.weight", "model.decoder.embed_positions.weight"):
+        w = ckpt[name].astype(np.float32)
+        w[:, [3, 17]] += 60.0 * r.standard_normal((w.shape[0], 2)).astype(np.float32) * 0.05 + np.array([40.0, -55.0], np.float32)
+        ckpt[name] = w.astype(np.float16)
+    ids, cu = synthetic_batch(spec, [1, 7, 33, 64, 129, 150], seed=9)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    got = sc.score(ids, cu)
+    want = OracleOPTScorer(spec, ckpt, dtype=torch.float64).score(ids, cu)
+    scale = max(1.0, float(np.abs(want).max()))
+    rel = float(np.abs(got - want).max()) / scale
+    print(f"{variant}: score range {np.abs(want).max():.2f}, max rel err {rel:.2e}")
+    assert np.isfinite(got).all() and rel <= 2e-5
