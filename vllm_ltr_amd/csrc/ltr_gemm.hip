@@ -282,12 +282,17 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
 #if !LTR_MFMA16
   const int lq = lane & 31, lh = lane >> 5;
 #endif
-  const int erow = lane >> 3, ecol = (lane & 7) * 8;
-  const int ccol = n0 + wc * 64 + ecol;
+  // Column ownership of a lane in the read-back (two float4 per row): split outputs need 8 CONSECUTIVE
+  // columns (one 16-byte store per fp16 plane: 8 lanes = a 128-B row piece); f32-only outputs take columns
+  // 4k..4k+3 and 32+4k..32+4k+3 instead, so that each of the two f32 stores / residual loads of the 8 lanes
+  // of a row covers one full 128-byte line (with 8 consecutive columns they interleave in 16-byte pieces).
+  const bool wide = ep.out_hi == nullptr;
+  const int erow = lane >> 3, ecol = (lane & 7) * (wide ? 4 : 8), ecol_b = wide ? ecol + 32 : ecol + 4;
+  const int ccol = n0 + wc * 64 + ecol, ccol_b = n0 + wc * 64 + ecol_b;
   float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
   if (ep.bias && ccol < N) {
     bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
-    bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol + 4);
+    bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
   }
   __syncthreads();
 #pragma unroll
@@ -321,12 +326,12 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
         gr[it] = grow;
         o[it] = (size_t)grow * N + ccol;
         va[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
-        vb[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol + 4);
+        vb[it] = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
         ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         rb[it] = ra[it];
         if (ep.resid && ok[it]) {
           ra[it] = *reinterpret_cast<const float4*>(ep.resid + o[it]);
-          rb[it] = *reinterpret_cast<const float4*>(ep.resid + o[it] + 4);
+          rb[it] = *reinterpret_cast<const float4*>(ep.resid + o[it] + (ecol_b - ecol));
         }
       }
 #pragma unroll
@@ -342,7 +347,7 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
         x[4] += rb[it].x; x[5] += rb[it].y; x[6] += rb[it].z; x[7] += rb[it].w;
         if (ep.out_f32) {
           *reinterpret_cast<float4*>(ep.out_f32 + o[it]) = make_float4(x[0], x[1], x[2], x[3]);
-          *reinterpret_cast<float4*>(ep.out_f32 + o[it] + 4) = make_float4(x[4], x[5], x[6], x[7]);
+          *reinterpret_cast<float4*>(ep.out_f32 + o[it] + (ecol_b - ecol)) = make_float4(x[4], x[5], x[6], x[7]);
         }
         if (ep.out_hi) {
           __half h[8], l[8];
