@@ -30,6 +30,22 @@ template <> struct Vec8<float> {
   }
 };
 
+template <typename T> struct Vec4;   // 4 consecutive table elements -> 4 floats
+template <> struct Vec4<__half> {
+  static __device__ __forceinline__ void load(const __half* p, float (&v)[4]) {
+    uint2 raw = *reinterpret_cast<const uint2*>(p);
+    const __half2* h = reinterpret_cast<const __half2*>(&raw);
+    float2 f0 = __half22float2(h[0]), f1 = __half22float2(h[1]);
+    v[0] = f0.x; v[1] = f0.y; v[2] = f1.x; v[3] = f1.y;
+  }
+};
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+};
+
 __device__ __forceinline__ void store8_f32(float* p, const float (&v)[8]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -62,13 +78,13 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(
   const WT* prow = pos_table + (size_t)pos * H;
   float* hrow = hidden + (size_t)t * H;
   if (!PROJ) {
-    for (int c = lane * 8; c < H; c += 512) {
-      float a[8], b[8];
-      Vec8<WT>::load(trow + c, a);
-      Vec8<WT>::load(prow + c, b);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] += b[i];
-      store8_f32(hrow + c, a);
+    // 4 columns per lane: every f32 store instruction writes 1 KiB of contiguous line-complete memory
+    // (8 columns per lane = two float4 stores that interleave in 16-byte pieces)
+    for (int c = lane * 4; c < H; c += 256) {
+      float a[4], b[4];
+      Vec4<WT>::load(trow + c, a);
+      Vec4<WT>::load(prow + c, b);
+      *reinterpret_cast<float4*>(hrow + c) = make_float4(a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]);
     }
   } else {
     for (int c = lane * 8; c < H; c += 512) {
