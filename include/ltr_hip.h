@@ -260,6 +260,16 @@ int ltr_reserve_select(const int32_t* perm, const int32_t* n_selected, const uin
                        uint8_t* action_out, int32_t* n_exec_out, int32_t* blocks_required_out,
                        void* stream);
 
+/* Next row in scope: the ListMLE loss the reference fine-tunes the predictor with
+ * (train/allrank/models/losses/listMLE.py:23-54, called by train/trainer.py:125-150) and its gradient
+ * w.r.t. the predictions.  y_pred, y_true f32 [B, S]; shuffle int32 [S] = the random permutation of :33
+ * (an input, so results are reproducible; equal labels keep the shuffled order); items with
+ * y_true == pad_value are masked.  loss_out f32 [1] = mean over slates; row_loss_out f32 [B] (scratch and
+ * per-slate losses); grad_out f32 [B, S] or NULL.  S <= 4096. */
+int ltr_listmle(const float* y_pred, const float* y_true, const int32_t* shuffle, int32_t B, int32_t S,
+                float eps, float pad_value, float* loss_out, float* row_loss_out, float* grad_out,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -379,6 +379,49 @@ def reserve_fixture():
     np.savez_compressed(os.path.join(GOLD, "reserve_calls.npz"), **out)
 
 
+def listmle_fixture():
+    """The reference's listMLE (train/allrank/models/losses/listMLE.py) and its autograd gradient on seeded
+    slates, with torch.randperm replaced by a recorded permutation."""
+    # Load the reference's listMLE.py itself (by path).  Its package __init__ chain pulls torchvision / gcsfs,
+    # absent here, for code the loss never touches, so the two constants it imports are provided through
+    # stand-in parent modules with the values of allrank/models/losses/__init__.py:17 and
+    # allrank/data/dataset_loading.py:31.
+    import importlib.util
+    for name in ("allrank", "allrank.data", "allrank.data.dataset_loading", "allrank.models", "allrank.models.losses"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["allrank.data.dataset_loading"].PADDED_Y_VALUE = -1
+    sys.modules["allrank.models.losses"].DEFAULT_EPS = 1e-10
+    spec_ = importlib.util.spec_from_file_location("ref_listMLE", "/root/reference/train/allrank/models/losses/listMLE.py")
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    out = {}
+    # labels are distinct inside a slate: with ties the reference's result depends on the tie order of
+    # torch.sort (unstable; implementation specific), which is why it shuffles first
+    cases = [("single_slate", 1, 24, False, False), ("pad3", 3, 40, False, True), ("long", 2, 300, False, False),
+             ("all_pad_tail", 2, 17, False, True), ("batch64", 64, 32, False, True)]
+    for name, B, S, ties, pad in cases:
+        rs = np.random.RandomState(abs(hash(name)) % 1000 + 7)
+        pred = rs.standard_normal((B, S)).astype(np.float32) * 2
+        true = (rs.randint(0, 6, (B, S)) if ties else np.stack([rs.permutation(S) for _ in range(B)])).astype(np.float32)
+        if pad:
+            for b in range(B):
+                true[b, rs.randint(S // 2, S):] = -1
+        perm = rs.permutation(S)
+        real = torch.randperm
+        torch.randperm = lambda n, *a, **k: torch.from_numpy(perm.copy())
+        try:
+            yp = torch.tensor(pred, requires_grad=True)
+            loss = mod.listMLE(yp, torch.tensor(true))
+            loss.backward()
+        finally:
+            torch.randperm = real
+        out[f"{name}_pred"], out[f"{name}_true"], out[f"{name}_perm"] = pred, true, perm.astype(np.int32)
+        out[f"{name}_loss"], out[f"{name}_grad"] = np.float32(loss.item()), yp.grad.numpy()
+        print(f"listMLE {name}: B={B} S={S} loss={loss.item():.6f}")
+    out["names"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(GOLD, "listmle.npz"), **out)
+
+
 def config_fixture():
     """Round-trip the shipped predictor configs through the reference's
     PrefillPredictorConfig.from_json (config_predictor.py:136-147) and record the
@@ -446,6 +489,8 @@ if __name__ == "__main__":
         ltr_head_fixture()
     if args.only in ("", "reserve"):
         reserve_fixture()
+    if args.only in ("", "listmle"):
+        listmle_fixture()
     if args.only in ("", "score"):
         edge = [1, 2, 4, 5, 63, 64, 65, 100, 3, 128, 17, 1, 31, 32, 33, 150]
         score_fixture("tiny_pre_ln", OPTSpec.tiny_pre_ln(), edge, 11)

@@ -1,0 +1,47 @@
+"""ListMLE loss: oracle vs the reference's recorded values (CPU), HIP kernel vs both (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.listmle import listmle as oracle_listmle
+from util import GOLDEN
+
+
+def _cases():
+    z = np.load(os.path.join(GOLDEN, "listmle.npz"))
+    return z, [str(n) for n in z["names"]]
+
+
+def test_oracle_matches_reference():
+    z, names = _cases()
+    for n in names:
+        loss, grad = oracle_listmle(z[f"{n}_pred"], z[f"{n}_true"], z[f"{n}_perm"])
+        ref = float(z[f"{n}_loss"])
+        assert abs(loss - ref) <= 2e-6 * abs(ref), n          # the reference computes in fp32
+        np.testing.assert_allclose(grad, z[f"{n}_grad"], atol=5e-6, rtol=0)
+
+
+@pytest.mark.gpu
+def test_hip_listmle_matches_reference_and_oracle():
+    from vllm_ltr_amd.train_loss import listmle
+    z, names = _cases()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for n in names:
+        loss, grad = listmle(t(z[f"{n}_pred"]), t(z[f"{n}_true"]), t(z[f"{n}_perm"]))
+        ref = float(z[f"{n}_loss"])
+        assert abs(float(loss.item()) - ref) <= 5e-6 * abs(ref), n
+        np.testing.assert_allclose(grad.cpu().numpy(), z[f"{n}_grad"], atol=1e-5, rtol=0)
+    # ties (stable order in the shuffled slate), padding anywhere, larger slates, loss only
+    r = np.random.RandomState(0)
+    for B, S in [(1, 1), (2, 2), (5, 257), (3, 1000), (2, 4096)]:
+        pred = (r.standard_normal((B, S)) * 3).astype(np.float32)
+        true = r.randint(-1, 5, (B, S)).astype(np.float32)
+        perm = r.permutation(S).astype(np.int32)
+        want_l, want_g = oracle_listmle(pred, true, perm)
+        loss, grad = listmle(t(pred), t(true), t(perm))
+        assert abs(float(loss.item()) - want_l) <= 2e-5 * max(1.0, abs(want_l)), (B, S)
+        np.testing.assert_allclose(grad.cpu().numpy(), want_g, atol=2e-5, rtol=5e-6)    # f32 kernel vs f64 oracle
+        loss2, none = listmle(t(pred), t(true), t(perm), with_grad=False)
+        assert none is None and float(loss2.item()) == float(loss.item())

@@ -21,7 +21,7 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
            "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
-           "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select")
+           "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle")
 
 
 class LtrError(RuntimeError):
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
     lib.ltr_profile_enable.argtypes = [vp, i32]
     lib.ltr_profile_read.argtypes = [vp, C.POINTER(ProfileStats), i32]
     lib.ltr_reserve_select.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.c_int64, vp, vp, vp, vp]
+    lib.ltr_listmle.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp]
     lib.ltr_head_create.argtypes = [C.POINTER(HeadDesc), C.POINTER(vp), i32, C.POINTER(vp)]
     lib.ltr_head_destroy.argtypes = [vp]
     lib.ltr_head_score.argtypes = [vp, vp, vp, i32, vp, vp]
