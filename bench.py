@@ -273,7 +273,7 @@ def main():
             "kernels": kernels,
             "model_tflop_per_step": (lin + att) / 1e12,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(spec, ckpt, ids, cu, args.starv, args.period)
         print(json.dumps(out))
     if world > 1:
