@@ -32,7 +32,7 @@ def test_hip_listmle_matches_reference_and_oracle():
         loss, grad = listmle(t(z[f"{n}_pred"]), t(z[f"{n}_true"]), t(z[f"{n}_perm"]))
         ref = float(z[f"{n}_loss"])
         assert abs(float(loss.item()) - ref) <= 5e-6 * abs(ref), n
-        np.testing.assert_allclose(grad.cpu().numpy(), z[f"{n}_grad"], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(grad.cpu().numpy(), z[f"{n}_grad"], atol=1e-5, rtol=1e-5)   # the reference itself is fp32
     # ties (stable order in the shuffled slate), padding anywhere, larger slates, loss only
     r = np.random.RandomState(0)
     for B, S in [(1, 1), (2, 2), (5, 257), (3, 1000), (2, 4096)]:
