@@ -61,8 +61,11 @@ struct ltr_model {
 
 namespace {
 
-// tokens per pass: measured plateau (GEMM 427 TF at 16k, 480 TF at >= 64k tokens per launch)
-constexpr int DEFAULT_CHUNK_TOKENS = 65536;
+// tokens per pass: 3 x 65,536, so that every GEMM of a layer is a whole number of 512-workgroup rounds.
+// Measured on the 8k-queue call: 247 ms at 64k tokens per pass, 242 at 128k, 240 at 192k-384k, 242 for a
+// single 709k-token pass (LayerNorm slows down once the residual stream of a pass outgrows the 256 MiB
+// Infinity Cache, attention keeps gaining from fewer, longer launches).  5.4 GB of workspace.
+constexpr int DEFAULT_CHUNK_TOKENS = 196608;
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
