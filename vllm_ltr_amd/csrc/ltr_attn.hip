@@ -35,40 +35,47 @@ constexpr int KT = 32;     // keys per LDS tile
 constexpr int D = 64;      // head size (OPT-125m/350m: 768/12 = 1024/16 = 64)
 constexpr float NEG = -1.0e30f;
 
-// Work list of the attention launch: blk_start[i] = sum_{j<i} ceil(L_j / qb) for i in [0, n_req]
-// and, per query block b, blk_desc[b] = (request, first query of the block, first token row of the
-// request in this chunk, request length).  The attention kernels read ONE 16-byte descriptor instead
-// of binary-searching the prefix table and then chasing cu_seqlens (every dependent global load
-// costs a workgroup of a short prompt ~1.5 us of its ~20 us life).
+// Work list of the attention launch: blk_start[n_req] = number of query blocks = sum_i ceil(L_i / qb) and,
+// per query block b, blk_desc[b] = (request, first query of the block, first token row of the request in this
+// chunk, request length).  The attention kernels read ONE 16-byte descriptor instead of binary-searching a
+// prefix table and then chasing cu_seqlens (every dependent global load costs a workgroup of a short prompt
+// ~1.5 us of its ~20 us life).  Blocks are listed longest first - a block's cost grows with its position k in
+// the request (it streams keys 0 .. (k+1) qb) - in three classes k >= 4, k in {2, 3}, k in {0, 1}, so that the
+// few long workgroups of a launch start early instead of forming its tail.
 __global__ void __launch_bounds__(1024) attn_blocks_kernel(const int32_t* __restrict__ cu, int n_req, int qb,
                                                            int32_t* __restrict__ blk_start,
                                                            int4* __restrict__ blk_desc) {
   __shared__ int s_w[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { carry = 0; blk_start[0] = 0; }
+  if (tid == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < n_req; base += 1024) {
-    int i = base + tid;
-    const int c0 = (i < n_req) ? cu[i] : 0, len = (i < n_req) ? cu[i + 1] - c0 : 0;
-    const int nb = (len + qb - 1) / qb;
-    int v = nb;
+  for (int cls = 0; cls < 3; ++cls) {
+    for (int base = 0; base < n_req; base += 1024) {
+      const int i = base + tid;
+      const int c0 = (i < n_req) ? cu[i] : 0, len = (i < n_req) ? cu[i + 1] - c0 : 0;
+      const int nb = (len + qb - 1) / qb;
+      const int lo = cls == 0 ? 4 : (cls == 1 ? 2 : 0);
+      const int hi = cls == 0 ? nb : (cls == 1 ? min(nb, 4) : min(nb, 2));
+      const int cnt = max(hi - lo, 0);
+      int v = cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-    if (lane == 63) s_w[wave] = v;
-    __syncthreads();
-    int off = carry;
-    for (int w = 0; w < wave; ++w) off += s_w[w];
-    v += off;
-    if (i < n_req) {
-      blk_start[i + 1] = v;
-      const int t0 = c0 - cu[0];
-      for (int k = 0; k < nb; ++k) blk_desc[v - nb + k] = make_int4(i, k * qb, t0, len);
+      for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+      if (lane == 63) s_w[wave] = v;
+      __syncthreads();
+      int off = carry;
+      for (int w = 0; w < wave; ++w) off += s_w[w];
+      v += off;
+      if (cnt > 0) {
+        const int t0 = c0 - cu[0];
+        for (int k = lo; k < hi; ++k) blk_desc[v - cnt + (k - lo)] = make_int4(i, k * qb, t0, len);
+      }
+      __syncthreads();
+      if (tid == 1023) carry = v;
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid == 1023) carry = v;
-    __syncthreads();
   }
+  if (tid == 0) blk_start[n_req] = carry;
 }
 
 template <bool SPLIT>
