@@ -21,6 +21,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-gpu-rdc"] + os.environ.get("LTR_HIPCC_EXTRA", "").split()
 
 
+# per-file flags: the attention kernel is bound by per-wave latency (a few hundred dependent VALU / LDS / MFMA
+# instructions per key tile) and gains 6 % from the ILP-maximising scheduler; the GEMM loses 3 % with it
+PER_FILE_FLAGS = {"ltr_attn.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -32,7 +37,7 @@ def _compile(src: str, force: bool) -> str:
     obj = os.path.join(HERE, src.replace(".hip", ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
