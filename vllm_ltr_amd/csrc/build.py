@@ -37,7 +37,8 @@ def _compile(src: str, force: bool) -> str:
     obj = os.path.join(HERE, src.replace(".hip", ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", obj]
+        extra = os.environ.get("LTR_FLAGS_" + src.split(".")[0].upper(), "").split()     # experiments: LTR_FLAGS_LTR_GEMM="..."
+        cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src, []), *extra, "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
