@@ -9,11 +9,13 @@
 
 One "step" = one COLD ranker call on the synthetic queue (every request unscored):
 predictor forward over all prompts (ltr_score) -> [N>1: RCCL all-gather of the score
-shards] -> starvation promote/demote + priority sort (ltr_rank_step) -> budget-walk
-prefix (ltr_budget_prefix) -> aging (ltr_age_update).  Inputs (token ids, cu_seqlens,
-queue state) are resident in HBM before the timed region.  N>1 is weak scaling: every
-rank scores its own 8k-request shard of an N*8k queue (BASELINE config 4 at N=8) and all
-ranks rank the whole gathered queue.
+shards] -> ltr_queue_step = starvation promote/demote + priority sort, budget-walk
+prefix, aging (two launches).  Inputs (token ids, cu_seqlens, queue state) are resident in
+HBM before the timed region.  N>1 is weak scaling and runs the PRODUCT's sharding logic
+(vllm_ltr_amd.distributed.ShardedScorer): one global queue of N*8k requests known to every
+rank (BASELINE config 4 at N=8), token-balanced contiguous shards from the shared
+cu_seqlens, each rank scores its shard, one all-gather of f32 scores, and every rank runs
+the same deterministic rank step on the whole gathered queue.
 
 Rank 0 prints one JSON line (contract in the task statement) with `roofline` for the
 dominant kernel and `cpu_baseline` (the oracle = CPU restatement of the reference, timed
@@ -39,11 +41,14 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
 
 
-def synthetic_queue(spec: OPTSpec, n: int, seed: int):
-    """BASELINE.md section 4 / SURVEY.md 8d: lengths clip(rint(exp(N(ln 64, 0.8))), 4, 1024);
-    ids [2] + randint(4, vocab)."""
+PROFILES = {"sharegpt": 64.0, "lmsys": 128.0}     # median prompt length of the lognormal profile
+
+
+def synthetic_queue(spec: OPTSpec, n: int, seed: int, profile: str = "sharegpt"):
+    """BASELINE.md section 4 / SURVEY.md 8d: lengths clip(rint(exp(N(ln 64, 0.8))), 4, 1024)
+    ("LMSYS-like", config 3: ln 128); ids [2] + randint(4, vocab)."""
     rs = np.random.RandomState(seed)
-    lens = np.clip(np.rint(np.exp(rs.normal(np.log(64.0), 0.8, n))), 4, 1024).astype(np.int64)
+    lens = np.clip(np.rint(np.exp(rs.normal(np.log(PROFILES[profile]), 0.8, n))), 4, 1024).astype(np.int64)
     g = torch.Generator().manual_seed(seed)
     T = int(lens.sum())
     ids = torch.randint(4, spec.vocab_size, (T,), generator=g, dtype=torch.int64).numpy()
@@ -107,6 +112,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--queue", type=int, default=8192, help="requests per GPU")
     ap.add_argument("--model", default="125m", choices=["125m", "350m"])
+    ap.add_argument("--profile", default="sharegpt", choices=sorted(PROFILES),
+                    help="prompt-length profile: sharegpt = ln 64 (BASELINE config 2), lmsys = ln 128 (config 3 with --model 350m)")
+    ap.add_argument("--min-shard", type=int, default=1024, help="ShardedScorer.min_requests_to_shard")
     ap.add_argument("--weight-dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--chunk-tokens", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,37 +146,41 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from vllm_ltr_amd.distributed import gather_scores
-    from vllm_ltr_amd.rank import DeviceQueue, budget_prefix
+    from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
+    from vllm_ltr_amd.rank import DeviceQueue
     from vllm_ltr_amd.scorer import HipOPTScorer
 
     spec = OPTSpec.opt_125m() if args.model == "125m" else OPTSpec.opt_350m()
     ckpt = seeded_checkpoint(spec, 0)
     scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)
 
-    # this rank's shard of the queue (weak scaling: args.queue requests per GPU)
+    # ONE global queue of args.queue requests per GPU, identical on every rank (SPMD: all ranks derive the shard
+    # map from the same cu_seqlens); the whole batch is resident on every rank, each rank scores its slice
     n_local = args.queue
     n_total = n_local * world
-    ids, cu, lens = synthetic_queue(spec, n_local, seed=rank)
+    ids, cu, lens = synthetic_queue(spec, n_total, seed=0, profile=args.profile)
     ids_d = torch.from_numpy(ids).to(dev)
     cu_d = torch.from_numpy(cu).to(dev)
-    shard_scores = torch.empty(n_local, dtype=torch.float32, device=dev)
+    sharded = ShardedScorer(scorer, dev, min_requests_to_shard=args.min_shard) if world > 1 else None
+    my_r0, my_r1 = shard_bounds(cu, world)[rank] if world > 1 and n_total >= args.min_shard else (0, n_total)
     queue = DeviceQueue(dev, starv=args.starv, period=args.period, capacity=n_total)
     queue.append(torch.zeros(n_total))
-    need_tokens = torch.from_numpy(np.tile(lens, world).astype(np.int32)).to(dev)
+    need_tokens = torch.from_numpy(lens.astype(np.int32)).to(dev)
     need_seqs = torch.ones(n_total, dtype=torch.int32, device=dev)
     perm = torch.empty(n_total, dtype=torch.int32, device=dev)
 
+    def rank_part():
+        # promote/demote + sort, budget-walk prefix, aging: ltr_queue_step, two launches
+        queue.step(need_tokens, need_seqs, 2048, 256, perm_out=perm)
+
     def step():
-        scorer.score_device(ids_d, cu_d, cu, out=shard_scores)
-        if world > 1:
+        if sharded is not None:
             # the one exchange step of the path: RCCL all-gather of f32 score shards over xGMI
-            queue._score[:n_total].copy_(gather_scores(shard_scores, [n_local] * world))
+            sharded_scores = sharded.score_device(ids_d, cu_d, cu)
+            queue._score[:n_total].copy_(sharded_scores)
         else:
-            queue._score[:n_total].copy_(shard_scores)
-        queue.rank(out=perm)
-        _, ran, _ = budget_prefix(perm, need_tokens, need_seqs, 2048, 256, want_granted=False)
-        queue.age(ran)
+            scorer.score_device(ids_d, cu_d, cu, out=queue._score[:n_total])
+        rank_part()
 
     def barrier():
         if world > 1:
@@ -196,9 +208,7 @@ def main():
     rk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for a, b in rk:
         a.record()
-        queue.rank(out=perm)
-        _, ran, _ = budget_prefix(perm, need_tokens, need_seqs, 2048, 256, want_granted=False)
-        queue.age(ran)
+        rank_part()
         b.record()
     torch.cuda.synchronize()
     rank_ms = sorted(a.elapsed_time(b) for a, b in rk)
@@ -211,10 +221,8 @@ def main():
     sk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10 if k_new else 0)]
     for i, (a, b) in enumerate(sk):
         a.record()
-        queue._score[:k_new].copy_(scorer.score_device(ids_k, cu_k_d, cu_k))
-        queue.rank(out=perm)
-        _, ran, _ = budget_prefix(perm, need_tokens, need_seqs, 2048, 256, want_granted=False)
-        queue.age(ran)
+        scorer.score_device(ids_k, cu_k_d, cu_k, out=queue._score[:k_new])
+        rank_part()
         b.record()
     torch.cuda.synchronize()
     if k_new:
@@ -226,7 +234,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        lin, att = model_flops(spec, lens)
+        lin, att = model_flops(spec, lens[my_r0:my_r1])        # this rank's shard: what its profiler timed
         gemm = prof["gemm"]
         gemm_tflops = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
         kernels = {}
@@ -240,6 +248,19 @@ def main():
             else:
                 kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
                                   gbs=rate / 1e9, frac_hbm=rate / 1e9 / PEAK_HBM_GBS)
+        if "embed" in kernels:
+            # SURVEY.md 8d counts 4616 B per token for the gather (a 2-byte activation row out); this kernel writes an
+            # f32 residual row (6152 B, the `gbs` above).  The fraction on SURVEY's own bytes:
+            w = 2.0 if args.weight_dtype == "f16" else 4.0
+            survey_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * w
+            ours_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * 4.0
+            kernels["embed"]["frac_hbm_survey_bytes"] = kernels["embed"]["frac_hbm"] * survey_b / ours_b
+        # steady rank step (nothing new to score): 37 B per request per step algorithmic
+        rk_us = rank_ms[len(rank_ms) // 2] * 1e3
+        kernels["rank_step"] = dict(us_per_step=rk_us, launches_per_step=2 if n_total <= 12288 else 9,
+                                    gbs=37.0 * n_total / (rk_us * 1e-6) / 1e9,
+                                    frac_hbm=37.0 * n_total / (rk_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                                    note="latency-bound: two dependent launches over a few hundred KB")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         if os.path.exists(tpath):
@@ -261,9 +282,11 @@ def main():
             "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if args.weight_dtype == "f16" else "f32",
             "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths, random token ids)",
             "config": {"workload": f"OPT-{args.model} predictor, {n_local} synthetic queue per GPU "
-                                   f"({n_total} total), cold ranker call", "queue_per_gpu": n_local,
-                       "tokens_per_gpu": int(cu[-1]), "starv": args.starv, "period": args.period,
-                       "parallelism": f"request-sharded dp{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
+                                   f"({n_total} total, {args.profile} length profile), cold ranker call",
+                       "queue_per_gpu": n_local, "queue_total": n_total, "tokens_total": int(cu[-1]),
+                       "tokens_rank0_shard": int(cu[my_r1] - cu[my_r0]), "starv": args.starv, "period": args.period,
+                       "parallelism": f"request-sharded dp{world}" + (", token-balanced shards of one global queue, "
+                                                                       "RCCL all-gather of scores" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": "gemm_f16s_kernel" if args.weight_dtype == "f16" else "gemm_f32_kernel",
                          "achieved": gemm_tflops, "peak": PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3,
                          "unit": "TFLOP/s", "frac": gemm_tflops / (PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LTR_ABI_VERSION 1
+#define LTR_ABI_VERSION 2
 
 enum {
   LTR_OK = 0,
@@ -94,10 +94,15 @@ const char* ltr_last_error(void);
  * vllm/model_executor/models/opt.py:411-444).  The library keeps the POINTERS (the
  * caller owns the weight memory and must keep it alive until ltr_destroy).  With
  * LTR_W_F16 the dense-layer weights (QKV / out_proj / fc1 / fc2 / project_in) are also
- * copied once, on the default stream, into a library-owned GEMM-friendly layout: the
- * buffers must hold the final values when ltr_create is called. */
+ * copied once into a library-owned GEMM-friendly layout: the copy kernels run on `stream`
+ * (so they are ordered after the caller's own uploads on that stream) and ltr_create
+ * synchronises `stream` before returning.  The handle remembers the device that owns
+ * weights[0]; every handle-based call makes that device current for its launches and
+ * restores the caller's device afterwards, so a handle of device 1 can be used while
+ * device 0 is current.  (Handle-less entry points - ltr_rank_step etc. - launch on the
+ * current device like any HIP launch: make the device of their pointers current first.) */
 int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights,
-               ltr_handle* out);
+               void* stream, ltr_handle* out);
 int ltr_destroy(ltr_handle h);
 
 /* Workspace sizing.  kind: */
@@ -120,6 +125,9 @@ int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens);
  *   cu_seqlens_host  the same array in host memory (the caller built it there);
  *               lets the library cut request-aligned chunks without a device sync.
  *               NULL: the library copies it back (one synchronising hipMemcpy).
+ *   max_len     the caller's bound on L_i (ModelRunner's max_prompt_len, model_runner.py:383-395);
+ *               a request longer than it is rejected with LTR_E_INVAL.  <= 0: no bound beyond
+ *               the position table.
  *   scores_out  f32 [N]: rank mode logits[:,0] (opt.py:408); class mode (num_labels>1)
  *               float(argmax_j logits[:, j]) (opt.py:394-395)
  *   logits_out  f32 [N, num_labels] or NULL (raw head output, for tests/telemetry)  */
@@ -127,6 +135,14 @@ int ltr_score(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
               const int32_t* cu_seqlens_host, int32_t N, int32_t T, int32_t max_len,
               float* scores_out, float* logits_out, void* workspace, size_t ws_bytes,
               void* stream);
+
+/* Deferred input errors.  ltr_score is asynchronous, so a token id outside [0, vocab_size) -
+ * on which the reference's F.embedding raises (vocab_parallel_embedding.py:95-106) - cannot be
+ * reported by the call that meets it: the embedding kernel flags it (and reads row 0 / the last
+ * row instead of faulting; the scores of that call are then meaningless).  ltr_status
+ * synchronises `stream`, returns LTR_E_INVAL if any forward since the previous ltr_status saw
+ * such an id (LTR_OK otherwise) and clears the flag.  Call it wherever the scores are read. */
+int ltr_status(ltr_handle h, void* stream);
 
 /* Same forward stopped after `n_layers` decoder layers (n_layers < 0: all), writing the
  * f32 hidden states [T, H] (before final LN / project_out).  Test / debugging hook for
@@ -157,6 +173,13 @@ int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, 
 
 /* One ranking step over the queued requests: the body of
  * Scheduler._get_opt_ordered_requests after scoring (vllm/core/scheduler.py:984-998).
+ *
+ * Device-resident queue state: scores / pri / idle / runs are SLOT arrays that persist across
+ * scheduler steps (a request keeps its slot from arrival to completion; new slots start at
+ * pri = idle = runs = 0, scheduler.py:372-374).  `members` int32 [N] lists the slot of every
+ * queued request in the order list(waiting)+list(running)+list(swapped) (scheduler.py:985,996);
+ * position i in `members` is what "input index", `tiebreak[i]` and perm_out refer to.
+ * members NULL: slot == position (the arrays ARE the concatenation).
  *   1. if starv != -1, per request (in place, scheduler.py:986-993):
  *        idle >= starv            -> pri = -1, idle = 0, runs = period
  *        elif pri == -1, runs <= 0 -> pri = 0
@@ -167,18 +190,34 @@ int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, 
  *      For the tpt/rtpt orders (scheduler.py:948,961) pass the rank of request_id under
  *      string comparison as tiebreak; LTR_RANK_ASCENDING sorts by +score (ropt/rtpt, :1015).
  *      tiebreak values must be < 2^31.  NaN scores sort after every number.
- *   scores f32 [N]; pri/idle/runs int32 [N]; perm_out int32 [N], perm_out[k] = input index
- *   of the k-th request to schedule. */
+ *   scores f32, pri/idle/runs int32: slot arrays; perm_out int32 [N], perm_out[k] = position
+ *   (index into members) of the k-th request to schedule.
+ *   workspace: ltr_workspace_bytes(NULL, LTR_WS_RANK, N, 0) bytes (only touched above 12,288 requests). */
 enum { LTR_RANK_USE_PRI = 1, LTR_RANK_ASCENDING = 2 };
 int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs,
-                  const uint32_t* tiebreak, int32_t N, int32_t starv, int32_t period,
-                  uint32_t flags, int32_t* perm_out, void* workspace, size_t ws_bytes,
-                  void* stream);
+                  const uint32_t* tiebreak, const int32_t* members, int32_t N, int32_t starv,
+                  int32_t period, uint32_t flags, int32_t* perm_out, void* workspace,
+                  size_t ws_bytes, void* stream);
 
 /* Post-schedule aging, the loop at the end of Scheduler._general_schedule
- * (vllm/core/scheduler.py:1358-1365): ran[i] != 0 -> (pri == -1: runs -= 1), idle = 0;
- * else idle += 1.  ran u8 [N]. */
-int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int32_t N,
+ * (vllm/core/scheduler.py:1358-1365) over the N queued requests (members as above):
+ * ran -> (pri == -1: runs -= 1), idle = 0; else idle += 1.  Which requests ran is given either
+ * as ran u8 [N] by position, or (ran NULL) as ran_slots int32 [n_ran], the ASCENDING list of the
+ * slots of `running_this_step` (<= max_num_seqs entries instead of an N-byte mask). */
+int ltr_age_update(const uint8_t* ran, const int32_t* ran_slots, int32_t n_ran, int32_t* pri,
+                   int32_t* idle, int32_t* runs, const int32_t* members, int32_t N, void* stream);
+
+/* A whole steady scheduler step on the device-resident queue in two launches: ltr_rank_step, then
+ * ltr_budget_prefix over the resulting order (same arguments, below) and ltr_age_update with the
+ * selection as `ran` - i.e. scheduler.py:984-998, :1137-1211 and :1358-1365 with nothing handed
+ * back to the host in between.  new_tokens / new_seqs / chunkable are indexed by position;
+ * outputs as in ltr_rank_step and ltr_budget_prefix (ran_out / granted_out nullable). */
+int ltr_queue_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs,
+                   const uint32_t* tiebreak, const int32_t* members, int32_t N, int32_t starv,
+                   int32_t period, uint32_t flags, const int32_t* new_tokens,
+                   const int32_t* new_seqs, const uint8_t* chunkable, int64_t token_budget,
+                   int64_t max_num_seqs, int32_t* perm_out, int32_t* n_selected_out,
+                   uint8_t* ran_out, int32_t* granted_out, void* workspace, size_t ws_bytes,
                    void* stream);
 
 /* Next row in scope: the hidden-state learning-to-rank head of
@@ -228,14 +267,18 @@ int ltr_profile_read(ltr_handle h, ltr_profile_stats* out, int32_t reset);
  * Scheduler._general_schedule makes over the ranked order (scheduler.py:1137-1211, with
  * _get_num_new_tokens :1867-1888 and SchedulingBudget.can_schedule :51-55), as one scan:
  * request k of perm is selected iff for every j <= k: new_tokens_j > 0,
- * sum_{i<j} new_tokens_i < token_budget (a chunked prefill is granted
- * min(need, remaining)), sum_{i<=j} new_seqs_i <= max_num_seqs, and a group with
- * new_seqs > 1 (never chunked) fits whole; the walk stops at the first k that fails.
- *   new_tokens / new_seqs  int32 [N] indexed by request (not by rank)
+ * sum_{i<j} new_tokens_i < token_budget (a chunkable group is granted
+ * min(need, remaining)), sum_{i<=j} new_seqs_i <= max_num_seqs, and a group that is not
+ * chunkable fits whole; the walk stops at the first k that fails.
+ *   new_tokens / new_seqs  int32 [N] indexed by request (not by rank): un-chunked
+ *     _get_num_new_tokens and get_max_num_running_seqs()
+ *   chunkable u8 [N] or NULL: 1 iff the group has exactly one sequence in the walked status
+ *     (`len(seqs) == 1`, scheduler.py:1884).  NOT the same as new_seqs == 1: a WAITING prompt with
+ *     best_of > 1 has one sequence and new_seqs = best_of (sequence.py:500-504).  NULL: new_seqs <= 1.
  *   n_selected_out int32 [1]; ran_out u8 [N] or NULL (1 = selected; feeds ltr_age_update);
  *   granted_out int32 [N] or NULL (tokens granted this step, 0 if not selected). */
 int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs,
-                      int32_t N, int64_t token_budget, int64_t max_num_seqs,
+                      const uint8_t* chunkable, int32_t N, int64_t token_budget, int64_t max_num_seqs,
                       int32_t* n_selected_out, uint8_t* ran_out, int32_t* granted_out,
                       void* stream);
 

@@ -41,8 +41,13 @@ def listmle(y_pred, y_true, shuffle, eps=DEFAULT_EPS, pad=PADDED_Y_VALUE, with_g
         loss += obs.sum()
         if with_grad:
             w = np.where(mask, 0.0, 1.0 / (c + eps))
-            g = e * np.cumsum(w) - np.where(mask, 0.0, 1.0)              # d/dp_j of sum_i obs_i (max held fixed)
+            g = e * np.cumsum(w) - np.where(mask, 0.0, 1.0)              # d/dp_j of sum_i obs_i with the max held fixed
             g[mask] = 0.0
+            # ... plus the path through max_pred_values (:44-46), which autograd routes to the arg-max item:
+            # d/dm [log(C_i + eps) - (p_i - m)] = 1 - C_i / (C_i + eps) = eps / (C_i + eps).  Negligible while
+            # C_i >> eps; ~1 per trailing item once exp(p_i - max) < eps (score spread above ~23).
+            if not mask.all():
+                g[int(np.argmax(p))] += float((np.where(mask, 0.0, eps / (c + eps))).sum())
             gb = np.zeros(S)
             gb[order] = g                                                # back to shuffled positions
             grad[b, shuffle] = gb / B                                    # and to the original columns

@@ -162,12 +162,12 @@ def _mk_scheduler(schedule_type, max_tokens, max_seqs, blocks=4096, block_size=1
     return Scheduler(sc, cc, None)
 
 
-def _mk_sg(rid: str, plen: int, block_size=16):
+def _mk_sg(rid: str, plen: int, block_size=16, best_of: int = 1):
     from vllm import SamplingParams
     from vllm.sequence import Sequence, SequenceGroup
-    seq = Sequence(int(rid) if rid.isdigit() else abs(hash(rid)) % 10**6, "p", list(range(plen)),
-                   block_size)
-    return SequenceGroup(rid, [seq], SamplingParams(max_tokens=10**6, ignore_eos=True), time.time())
+    seq = Sequence(int(rid), "p", list(range(plen)), block_size)
+    return SequenceGroup(rid, [seq], SamplingParams(n=best_of, best_of=best_of, max_tokens=10**6, ignore_eos=True),
+                         time.time())
 
 
 def order_fixture():
@@ -234,13 +234,20 @@ def order_fixture():
 
 def steps_fixture():
     """Multi-step runs of the reference's full Scheduler.schedule() (= _general_schedule,
-    scheduler.py:1101-1373) with starvation control; per step we record the order
-    returned by _get_ordered_requests, which requests ran, and (pri, idle, runs) after
-    the aging loop (:1358-1365)."""
-    from vllm.sequence import Logprob
+    scheduler.py:1101-1373) with starvation control; per step we record the concatenation
+    list(waiting)+list(running)+list(swapped) the order is computed from (scheduler.py:985), the
+    order returned by _get_ordered_requests, what the budget walk sees per request (un-chunked new
+    tokens, new sequences, whether _get_num_new_tokens may chunk it: exactly one sequence in the
+    walked status, :1884), which requests ran with the tokens granted, and (pri, idle, runs) after
+    the aging loop (:1358-1365).  The last case holds best_of = 2 requests: a WAITING prompt has ONE
+    sequence but get_max_num_running_seqs() = 2 (sequence.py:500-504), so it is chunked although
+    new_seqs > 1; after its prefill the sequence is forked (what the engine's output processor does),
+    so its decode steps carry two RUNNING sequences and are not chunked."""
+    from vllm.sequence import Logprob, SequenceStatus
     runs_out = {}
-    for fi, (n, starv, period, max_seqs, max_tokens, steps, plen) in enumerate(
-            [(10, 3, 2, 4, 64, 12, 4), (48, 4, 2, 6, 96, 24, 8), (200, 6, 3, 16, 256, 30, 5)]):
+    cases = [(10, 3, 2, 4, 64, 12, (4, 4), 0.0), (48, 4, 2, 6, 96, 24, (8, 8), 0.0), (200, 6, 3, 16, 256, 30, (5, 5), 0.0),
+             (36, 5, 2, 8, 64, 40, (20, 150), 0.5)]
+    for fi, (n, starv, period, max_seqs, max_tokens, steps, (plo, phi), frac_bo2) in enumerate(cases):
         rs = np.random.RandomState(100 + fi)
         st = f"opt-xxx-starv{starv}-period{period}"
         s = _mk_scheduler(st, max_tokens, max_seqs)
@@ -249,14 +256,17 @@ def steps_fixture():
         ids = [str(i) for i in range(n)]
         table = {r: float(x) for r, x in zip(ids, sc)}
         s.aux_model = _StubAux(table)
-        sgs = [_mk_sg(r, plen) for r in ids]
-        by_id = {g.request_id: g for g in sgs}
+        plens = rs.randint(plo, phi + 1, n)
+        bo = np.where(rs.rand(n) < frac_bo2, 2, 1)
+        sgs = [_mk_sg(r, int(plens[i]), best_of=int(bo[i])) for i, r in enumerate(ids)]
         arrive_at = np.zeros(n, np.int32) if fi == 0 else np.sort(rs.randint(0, steps // 2, n)).astype(np.int32)
-        orders, rans, states, present, needs, nseqs, grants = [], [], [], [], [], [], []
+        orders, rans, states, present, needs, nseqs, grants, concats, chunkables = [], [], [], [], [], [], [], [], []
         captured = {}
         inner = s._get_ordered_requests
+        next_seq_id = [10**6]
 
         def spy():
+            captured["concat"] = [g.request_id for g in list(s.waiting) + list(s.running) + list(s.swapped)]
             o = inner()
             captured["order"] = [g.request_id for g in o]
             return o
@@ -266,25 +276,42 @@ def steps_fixture():
                 s.add_seq_group(sgs[i])
             # what the budget walk will see: un-chunked new tokens / new sequences per queued request
             # (_get_num_new_tokens before the min() with the remaining budget, scheduler.py:1878-1881)
-            nd = np.zeros(n, np.int32); nq = np.zeros(n, np.int32)
-            for g in list(s.waiting) + list(s.running) + list(s.swapped):
-                nd[int(g.request_id)] = sum(q.get_num_new_tokens() for q in g.get_seqs())
-                nq[int(g.request_id)] = g.get_max_num_running_seqs()
-            needs.append(nd); nseqs.append(nq)
+            nd = np.zeros(n, np.int32); nq = np.zeros(n, np.int32); ck = np.zeros(n, np.uint8)
+            for dq, status in ((s.waiting, SequenceStatus.WAITING), (s.running, SequenceStatus.RUNNING),
+                               (s.swapped, SequenceStatus.SWAPPED)):
+                for g in dq:
+                    seqs = g.get_seqs(status=status)
+                    nd[int(g.request_id)] = sum(q.get_num_new_tokens() for q in seqs)
+                    nq[int(g.request_id)] = g.get_max_num_running_seqs()
+                    ck[int(g.request_id)] = len(seqs) == 1
+            needs.append(nd); nseqs.append(nq); chunkables.append(ck)
             metas, out = s.schedule()
             ran = [x.seq_group.request_id for x in out.scheduled_seq_groups]
             gr = np.zeros(n, np.int32)
             for x, meta in zip(out.scheduled_seq_groups, metas):
-                gr[int(x.seq_group.request_id)] = meta.token_chunk_size      # tokens granted this step
+                # tokens charged to the budget for this group (the walk's num_new_tokens, scheduler.py:1159);
+                # = token_chunk_size x running sequences
+                gr[int(x.seq_group.request_id)] = meta.token_chunk_size * len(x.seq_group.get_seqs(status=SequenceStatus.RUNNING))
             grants.append(gr)
             for x, meta in zip(out.scheduled_seq_groups, metas):
-                x.seq_group.update_num_computed_tokens(meta.token_chunk_size)
-                if not x.seq_group.is_prefill():
-                    for seq in x.seq_group.get_seqs():
+                g = x.seq_group
+                was_prefill = g.is_prefill()
+                g.update_num_computed_tokens(meta.token_chunk_size)
+                if not g.is_prefill():
+                    for seq in g.get_seqs(status=SequenceStatus.RUNNING):
                         seq.append_token_id(1, {1: Logprob(0.0)})
+                    if was_prefill and g.sampling_params.best_of > g.num_seqs():
+                        # the engine forks the prompt sequence into best_of samples after the prefill
+                        # (llm_engine.py _process_sequence_group_outputs -> scheduler.fork_seq)
+                        parent = g.get_seqs(status=SequenceStatus.RUNNING)[0]
+                        child = parent.fork(next_seq_id[0]); next_seq_id[0] += 1
+                        g.add(child)
+                        s.fork_seq(parent, child)
             alive = [g.request_id for g in list(s.waiting) + list(s.running) + list(s.swapped)]
             o = np.full(n, -1, np.int32); o[:len(captured["order"])] = [int(r) for r in captured["order"]]
             orders.append(o)
+            c = np.full(n, -1, np.int32); c[:len(captured["concat"])] = [int(r) for r in captured["concat"]]
+            concats.append(c)
             r = np.zeros(n, np.uint8); r[[int(x) for x in ran]] = 1
             rans.append(r)
             p = np.zeros(n, np.uint8); p[[int(x) for x in alive]] = 1
@@ -294,14 +321,18 @@ def steps_fixture():
                 if hasattr(g, "pri"):
                     stt[int(g.request_id)] = (g.pri, g.idle, g.runs)
             states.append(stt)
-        print(f"steps case {fi}: n={n} first orders {orders[0][:6]} ... step3 {orders[min(3, steps-1)][:8]}")
+        nch = int(sum(((np.stack(grants)[t] > 0) & (np.stack(grants)[t] < np.stack(needs)[t])).sum() for t in range(steps)))
+        nbo = int(sum(((np.stack(nseqs)[t] > 1) & (np.stack(grants)[t] > 0)).sum() for t in range(steps)))
+        print(f"steps case {fi}: n={n} first orders {orders[0][:6]} ... step3 {orders[min(3, steps-1)][:8]}; "
+              f"chunked grants {nch}, grants to new_seqs>1 groups {nbo}")
         runs_out.update({f"f{fi}_score": sc, f"f{fi}_starv": np.int64(starv), f"f{fi}_period": np.int64(period),
-                         f"f{fi}_arrive_at": arrive_at, f"f{fi}_orders": np.stack(orders),
+                         f"f{fi}_arrive_at": arrive_at, f"f{fi}_orders": np.stack(orders), f"f{fi}_concat": np.stack(concats),
                          f"f{fi}_ran": np.stack(rans), f"f{fi}_present": np.stack(present),
                          f"f{fi}_states": np.stack(states), f"f{fi}_need_tokens": np.stack(needs),
-                         f"f{fi}_need_seqs": np.stack(nseqs), f"f{fi}_granted": np.stack(grants), f"f{fi}_token_budget": np.int64(max_tokens),
+                         f"f{fi}_need_seqs": np.stack(nseqs), f"f{fi}_chunkable": np.stack(chunkables),
+                         f"f{fi}_granted": np.stack(grants), f"f{fi}_token_budget": np.int64(max_tokens),
                          f"f{fi}_max_num_seqs": np.int64(max_seqs)})
-    runs_out["n_cases"] = np.int64(3)
+    runs_out["n_cases"] = np.int64(len(cases))
     np.savez_compressed(os.path.join(GOLD, "rank_steps.npz"), **runs_out)
 
 
@@ -397,11 +428,12 @@ def listmle_fixture():
     out = {}
     # labels are distinct inside a slate: with ties the reference's result depends on the tie order of
     # torch.sort (unstable; implementation specific), which is why it shuffles first
-    cases = [("single_slate", 1, 24, False, False), ("pad3", 3, 40, False, True), ("long", 2, 300, False, False),
-             ("all_pad_tail", 2, 17, False, True), ("batch64", 64, 32, False, True)]
-    for name, B, S, ties, pad in cases:
-        rs = np.random.RandomState(abs(hash(name)) % 1000 + 7)
-        pred = rs.standard_normal((B, S)).astype(np.float32) * 2
+    cases = [("single_slate", 1, 24, False, False, 2.0), ("pad3", 3, 40, False, True, 2.0), ("long", 2, 300, False, False, 2.0),
+             ("all_pad_tail", 2, 17, False, True, 2.0), ("batch64", 64, 32, False, True, 2.0),
+             ("wide_spread", 4, 48, False, True, 14.0)]
+    for ci, (name, B, S, ties, pad, scale) in enumerate(cases):
+        rs = np.random.RandomState(1000 + 7 * ci)      # fixed per case: the fixture regenerates bit-identically
+        pred = rs.standard_normal((B, S)).astype(np.float32) * scale
         true = (rs.randint(0, 6, (B, S)) if ties else np.stack([rs.permutation(S) for _ in range(B)])).astype(np.float32)
         if pad:
             for b in range(B):

@@ -173,19 +173,24 @@ def string_rank(request_ids: Sequence[str]) -> np.ndarray:
 
 
 # ---- budget walk (next row in scope) --------------------------------
-def budget_walk(order_need_tokens, order_need_seqs, token_budget: int, max_num_seqs: int):
+def budget_walk(order_need_tokens, order_need_seqs, token_budget: int, max_num_seqs: int, order_chunkable=None):
     """Literal restatement of the selection loop of Scheduler._general_schedule
     (scheduler.py:1137-1211) for one ranked order: per request, in order,
     ``num_new_tokens = min(need, budget.remaining_token_budget())`` when the group has a
-    single sequence (_get_num_new_tokens, :1867-1888, enable_chunking=True at :1128),
+    single sequence IN THE WALKED STATUS (``len(seqs) == 1`` in _get_num_new_tokens, :1867-1888,
+    enable_chunking=True at :1128) - ``order_chunkable``; a WAITING prompt with best_of > 1 has one
+    sequence but ``new_seqs = best_of`` (sequence.py:500-504), so the flag is NOT ``new_seqs == 1``
+    (None keeps that approximation for callers that only have single-sequence groups);
     ``break`` if ``num_new_tokens == 0 or not budget.can_schedule(...)`` (:51-55).
     Returns (n_selected, granted tokens per position)."""
     used_tokens = 0
     used_seqs = 0
     granted = []
-    for need, nseq in zip(order_need_tokens, order_need_seqs):
+    if order_chunkable is None:
+        order_chunkable = [nseq <= 1 for nseq in order_need_seqs]
+    for need, nseq, chunk in zip(order_need_tokens, order_need_seqs, order_chunkable):
         n = int(need)
-        if nseq == 1:
+        if chunk:
             n = min(n, token_budget - used_tokens)
         if n == 0 or not (used_tokens + n <= token_budget and used_seqs + nseq <= max_num_seqs):
             break

@@ -1,0 +1,93 @@
+"""-m gpu: the N-rank ranking path with the REAL HIP predictor, two processes sharing the one device of the
+GPU box (gloo for the control plane; production uses RCCL with one device per rank): shard map, per-rank scoring
+of its slice, score all-gather, identical rank step on every rank - gathered scores must equal the
+single-process scores bit for bit (a request's score does not depend on which other requests share its pass)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from collections import deque
+        from util import FakeSeqGroup, bench_lengths, synthetic_batch
+        from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
+        from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+        from vllm_ltr_amd.plugin import MI355XRanker
+        from vllm_ltr_amd.rank import DeviceQueue
+        from vllm_ltr_amd.scorer import HipOPTScorer
+        dev = torch.device("cuda:0")
+        spec = OPTSpec.tiny_pre_ln()
+        sc = HipOPTScorer(spec, seeded_checkpoint(spec, 3), "cuda:0", "f16")
+        n = 700
+        lens = bench_lengths(n, seed=5, mu=24.0).clip(1, 150)
+        ids, cu = synthetic_batch(spec, lens.tolist(), 6)              # identical on every rank (SPMD)
+        ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+        single = sc.score_device(ids_d, cu_d, cu).cpu().numpy()        # what one process computes alone
+        sh = ShardedScorer(sc, dev, min_requests_to_shard=64)
+        got_dev = sh.score_device(ids_d, cu_d, cu)                     # device-resident batch (bench)
+        got_host = sh.score(ids, cu)                                   # host batch (each rank uploads its shard only)
+        small = sh.score_device(ids_d[:cu[10]], cu_d[:11], cu[:11])    # below the threshold: rank 0 scores, broadcast
+        ok = (np.array_equal(got_dev.cpu().numpy(), single) and np.array_equal(got_host.cpu().numpy(), single)
+              and np.array_equal(small.cpu().numpy(), single[:10]))
+        b = shard_bounds(cu, world)
+        # the rank step on the gathered queue is deterministic: same permutation everywhere
+        queue = DeviceQueue(dev, starv=3, period=2, capacity=n)
+        queue.append(got_dev)
+        perm = queue.rank().cpu().numpy().tolist()
+        # the plug-in with group=: obtain_aux_scores shards the same way
+        ranker = MI355XRanker(sc, "opt-xxx-starv3-period2", max_length=160, group=dist.group.WORLD, min_requests_to_shard=64)
+        groups = [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(n)]
+
+        class Sched:
+            pass
+        s = Sched()
+        s.waiting, s.running, s.swapped = deque(groups), deque(), deque()
+        ranker.install(s)
+        order = [g.request_id for g in s._get_ordered_requests()]
+        plug_ok = np.array_equal(np.array([g.aux_model_score for g in groups], np.float32), single)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (perm, order))
+        same = all(g == gathered[0] for g in gathered)
+        q.put((rank, ok, plug_ok, same, b[rank], order[:5] == [str(i) for i in perm[:5]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_sharded_hip_scoring_on_one_device():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort()
+    for rank, ok, plug_ok, same, bounds, head in res:
+        assert ok, f"rank {rank}: gathered scores differ from the single-process scores"
+        assert plug_ok, f"rank {rank}: plug-in scores differ"
+        assert same and head, f"rank {rank}: ranks disagree on the permutation"
+        assert 0 < bounds[1] - bounds[0] < 700
+    assert res[0][4][1] == res[1][4][0]          # contiguous shards

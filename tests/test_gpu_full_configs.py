@@ -1,0 +1,133 @@
+"""-m gpu: the BASELINE configurations at FULL size through the C ABI.
+
+config 2: OPT-125m predictor, 8,192-request synthetic queue (ln 64 lengths, T = 708,977 tokens): the exact call
+          `bench.py` times - four passes of <= 196,608 tokens.
+config 3: OPT-350m predictor, 8,192-request "LMSYS-like" queue (ln 128 lengths).
+
+The oracle cannot score 700k+ tokens in test time, so parity at this size is established through
+size-independent properties - determinism, invariance of every score to how the batch is cut into passes
+(1 pass / 4 / many), the last-layer pruning against the unpruned forward - plus an oracle check (1e-4, the
+north_star tolerance) on >= 32 requests sampled across ALL passes, including the first and last request of
+each pass (where the multi-pass offsets of ltr_api.hip's forward_chunk are exercised)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.opt_scorer import OracleOPTScorer
+from util import bench_lengths
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEFAULT_CHUNK = 196608
+
+
+def _queue(spec, n, mu):
+    """bench.py's synthetic_queue (same generator, same seed 0)."""
+    lens = bench_lengths(n, seed=0, mu=mu)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(4, spec.vocab_size, (int(lens.sum()),), generator=g, dtype=torch.int64).numpy()
+    cu = np.zeros(n + 1, np.int32)
+    np.cumsum(lens, out=cu[1:])
+    ids[cu[:-1]] = 2
+    return ids, cu, lens
+
+
+def _passes(cu, cap):
+    """Request ranges of the passes ltr_score cuts (request-aligned, <= cap tokens; ltr_api.hip run_forward)."""
+    out, r0, n = [], 0, len(cu) - 1
+    while r0 < n:
+        r1 = r0
+        while r1 < n and int(cu[r1 + 1]) - int(cu[r0]) <= cap:
+            r1 += 1
+        out.append((r0, r1))
+        r0 = r1
+    return out
+
+
+def _sample(passes, n, k_extra, seed):
+    idx = set()
+    for r0, r1 in passes:
+        idx.update((r0, r1 - 1))
+    r = np.random.RandomState(seed)
+    idx.update(r.randint(0, n, k_extra).tolist())
+    return np.array(sorted(idx))
+
+
+def _oracle_scores(spec, ckpt, ids, cu, sample):
+    lens = np.diff(cu)[sample]
+    ids_s = np.concatenate([ids[cu[i]:cu[i + 1]] for i in sample])
+    cu_s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    return OracleOPTScorer(spec, ckpt).score_packed(ids_s, cu_s, max_tokens=2048)
+
+
+def test_config2_opt125m_8k_queue_full_size():
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    dev = "cuda:0"
+    spec = OPTSpec.opt_125m()
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = _queue(spec, 8192, 64.0)
+    assert int(cu[-1]) == 708977                                    # the bench workload
+    sc = HipOPTScorer(spec, ckpt, dev, "f16")
+    ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+    s4 = sc.score_device(ids_d, cu_d, cu).cpu().numpy()             # default: 4 passes
+    passes = _passes(cu, DEFAULT_CHUNK)
+    assert len(passes) == 4
+    assert np.isfinite(s4).all()
+    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s4)          # deterministic
+    sc.set_chunk_tokens(65536)                                                          # 11 passes
+    assert len(_passes(cu, 65536)) == 11
+    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s4)
+    sc.set_chunk_tokens(1 << 20)                                                        # ONE 709k-token pass
+    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s4)
+    sc.set_chunk_tokens(0)
+    # last-layer pruning (ltr_score carries only the last-token rows through the tail of layer 12) against the
+    # unpruned forward of a whole pass, H = 768: pool the full hidden states of pass 2 (non-zero offsets)
+    r0, r1 = passes[1]
+    t0, t1 = int(cu[r0]), int(cu[r1])
+    cu_p = (cu[r0:r1 + 1] - t0).astype(np.int32)
+    h = torch.from_numpy(sc.hidden(ids[t0:t1], cu_p, n_layers=-1)).to(dev)
+    full = torch.empty(r1 - r0, device=dev)
+    sc.pool_head_device(h, torch.from_numpy(cu_p).to(dev), r1 - r0, full)
+    assert np.array_equal(full.cpu().numpy(), s4[r0:r1])
+    del h
+    # the oracle on requests from every pass, pass boundaries included
+    sample = _sample(passes, 8192, 28, seed=1)
+    assert len(sample) >= 32
+    want = _oracle_scores(spec, ckpt, ids, cu, sample)
+    err = float(np.abs(want - s4[sample]).max())
+    print(f"config 2 (OPT-125m, 8192 requests, {int(cu[-1])} tokens, 4 passes): oracle sample of {len(sample)} "
+          f"requests, max|d| = {err:.3e}")
+    assert err <= TOL
+
+
+def test_config3_opt350m_8k_lmsys_like_queue_full_size():
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    dev = "cuda:0"
+    spec = OPTSpec.opt_350m()
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = _queue(spec, 8192, 128.0)                       # ln 64 -> ln 128
+    T = int(cu[-1])
+    sc = HipOPTScorer(spec, ckpt, dev, "f16")
+    ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+    s = sc.score_device(ids_d, cu_d, cu).cpu().numpy()
+    passes = _passes(cu, DEFAULT_CHUNK)
+    assert len(passes) >= 6 and np.isfinite(s).all()
+    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s)           # deterministic
+    sc.set_chunk_tokens(98304)                                                          # twice as many passes
+    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s)
+    sc.set_chunk_tokens(0)
+    # permutation of the requests: the score of a request does not depend on its neighbours
+    perm = np.random.RandomState(2).permutation(8192)
+    ids_p = np.concatenate([ids[cu[i]:cu[i + 1]] for i in perm])
+    cu_p = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.int32)
+    sp = sc.score_device(torch.from_numpy(ids_p).to(dev), torch.from_numpy(cu_p).to(dev), cu_p).cpu().numpy()
+    assert np.array_equal(sp, s[perm])
+    sample = _sample(passes, 8192, 16, seed=3)
+    assert len(sample) >= 28
+    want = _oracle_scores(spec, ckpt, ids, cu, sample)
+    err = float(np.abs(want - s[sample]).max())
+    print(f"config 3 (OPT-350m, 8192 requests, {T} tokens, {len(passes)} passes): oracle sample of {len(sample)} "
+          f"requests, max|d| = {err:.3e}")
+    assert err <= TOL

@@ -126,21 +126,25 @@ def test_multi_step_replay_of_reference_runs(dev):
         pri = torch.zeros(n, dtype=torch.int32, device=dev)
         idle = torch.zeros_like(pri); runs = torch.zeros_like(pri)
         sc = torch.from_numpy(score).to(dev)
+        concat = g("concat")
         for step in range(orders.shape[0]):
             want = orders[step][orders[step] >= 0]
-            members = torch.from_numpy(np.sort(want).astype(np.int64)).to(dev)
+            # slot order = list(waiting)+list(running)+list(swapped) as the reference built it (scheduler.py:985):
+            # ties in (pri, score) are broken by it, so the request ids must match exactly
+            # the state stays in per-request slots on the device for the whole run (slot = request id); each
+            # step only hands over `members`
+            members = torch.from_numpy(concat[step][concat[step] >= 0].astype(np.int32)).to(dev)
             if len(want):
-                p, i_, r_ = pri[members].contiguous(), idle[members].contiguous(), runs[members].contiguous()
-                perm = rank_step(sc[members].contiguous(), p, i_, r_, starv, period, ws)
-                pri[members], idle[members], runs[members] = p, i_, r_
+                perm = rank_step(sc, pri, idle, runs, starv, period, ws, members=members)
                 got = members[perm.long()].cpu().numpy()
-                key = lambda j: (int(pri[j]), -float(score[j]))
-                assert [key(j) for j in got] == [key(j) for j in want], f"case {fi} step {step}"
-            alive = torch.from_numpy(np.nonzero(present[step])[0]).to(dev)
+                assert got.tolist() == want.tolist(), f"case {fi} step {step}"
+            alive = torch.from_numpy(np.nonzero(present[step])[0].astype(np.int32)).to(dev)
             if alive.numel():
-                p, i_, r_ = pri[alive].contiguous(), idle[alive].contiguous(), runs[alive].contiguous()
-                age_update(torch.from_numpy(ran[step]).to(dev)[alive].contiguous(), p, i_, r_)
-                pri[alive], idle[alive], runs[alive] = p, i_, r_
+                if step % 2 == 0:     # ran as a mask by position ...
+                    age_update(torch.from_numpy(ran[step]).to(dev)[alive.long()].contiguous(), pri, idle, runs, members=alive)
+                else:                 # ... or as the ascending slot list of running_this_step
+                    rs_ = torch.from_numpy(np.nonzero(ran[step])[0].astype(np.int32)).to(dev)
+                    age_update(None, pri, idle, runs, members=alive, ran_slots=rs_)
                 st = torch.stack([pri, idle, runs], 1).cpu().numpy()
                 a = alive.cpu().numpy()
                 assert (st[a] == states[step][a]).all(), f"case {fi} step {step}"
@@ -156,13 +160,59 @@ def test_budget_prefix(dev, n, budget, max_seqs):
     if n > 50:
         need[r.randint(0, n, 2)] = 0
     seqs = np.ones(n, np.int32)
+    chunk = None
+    if n >= 100:                      # mixed groups: best_of > 1 prompts (chunkable, 2 seqs) and multi-sequence decodes
+        seqs = r.randint(1, 3, n).astype(np.int32)
+        chunk = ((seqs == 1) | (r.rand(n) < 0.5)).astype(np.uint8)
     nsel, ran, granted = budget_prefix(torch.from_numpy(perm).to(dev), torch.from_numpy(need).to(dev),
-                                       torch.from_numpy(seqs).to(dev), budget, max_seqs)
-    want_n, want_g = rs.budget_walk(need[perm], seqs[perm], budget, max_seqs)
+                                       torch.from_numpy(seqs).to(dev), budget, max_seqs,
+                                       chunkable=None if chunk is None else torch.from_numpy(chunk).to(dev))
+    want_n, want_g = rs.budget_walk(need[perm], seqs[perm], budget, max_seqs, None if chunk is None else chunk[perm])
     assert int(nsel.item()) == want_n
     ran = ran.cpu().numpy(); granted = granted.cpu().numpy()
     assert (ran[perm[:want_n]] == 1).all() and ran.sum() == want_n
     assert granted[perm[:want_n]].tolist() == want_g and granted.sum() == sum(want_g)
+
+
+@pytest.mark.parametrize("n,starv,period,sparse", [(1, 3, 2, False), (777, 5, 3, True), (8192, 200, 10, False),
+                                                    (8192, 7, 2, True), (12288, -1, 0, False), (30000, 9, 4, True)])
+def test_queue_step_two_launches_vs_oracle(dev, n, starv, period, sparse):
+    """ltr_queue_step (rank + budget-walk selection + promote/demote write-back + aging in two launches) over a
+    few consecutive steps against the oracle's separate functions; `sparse`: the queue occupies a random subset
+    of the slots and is visited in a random order (members)."""
+    from vllm_ltr_amd.rank import DeviceQueue
+    r = np.random.RandomState(n + starv)
+    cap = n * 2 if sparse else n
+    q = DeviceQueue(dev, starv=starv, period=period, capacity=cap)
+    score = r.standard_normal(cap).astype(np.float16).astype(np.float32)
+    q.append(torch.from_numpy(score))
+    pri = -(r.rand(cap) < 0.2).astype(np.int32)
+    idle = r.randint(0, max(2, 2 * max(starv, 1)), cap).astype(np.int32)
+    runs = r.randint(-2, period + 2, cap).astype(np.int32)
+    q._pri[:cap] = torch.from_numpy(pri).to(dev); q._idle[:cap] = torch.from_numpy(idle).to(dev)
+    q._runs[:cap] = torch.from_numpy(runs).to(dev)
+    members = r.permutation(cap)[:n].astype(np.int32) if sparse else None
+    mem_d = None if members is None else torch.from_numpy(members).to(dev)
+    sl = members.astype(np.int64) if sparse else np.arange(n)
+    for step in range(3):
+        need = r.randint(1, 64, n).astype(np.int32)
+        seqs = r.randint(1, 3, n).astype(np.int32)
+        chunk = ((seqs == 1) | (r.rand(n) < 0.5)).astype(np.uint8)
+        perm, nsel, ran, granted = q.step(torch.from_numpy(need).to(dev), torch.from_numpy(seqs).to(dev), 2048, 256,
+                                          members=mem_d, chunkable=torch.from_numpy(chunk).to(dev), want_granted=True)
+        p, i_, r_ = pri[sl].copy(), idle[sl].copy(), runs[sl].copy()
+        want = rs.rank_step_np(score[sl], p, i_, r_, starv, period)
+        assert (perm.cpu().numpy() == want).all(), step
+        wn, wg = rs.budget_walk(need[want], seqs[want], 2048, 256, chunk[want])
+        assert int(nsel.item()) == wn
+        wr = np.zeros(n, np.uint8); wr[want[:wn]] = 1
+        assert (ran.cpu().numpy() == wr).all()
+        g = granted.cpu().numpy()
+        assert g[want[:wn]].tolist() == wg and g.sum() == sum(wg)
+        rs.age_update_np(wr, p, i_, r_)
+        pri[sl], idle[sl], runs[sl] = p, i_, r_
+        assert (q._pri[:cap].cpu().numpy() == pri).all() and (q._idle[:cap].cpu().numpy() == idle).all()
+        assert (q._runs[:cap].cpu().numpy() == runs).all()            # slots outside the queue are untouched
 
 
 def test_budget_prefix_vs_reference_schedule(dev):
@@ -180,8 +230,9 @@ def test_budget_prefix_vs_reference_schedule(dev):
                 continue
             need = torch.from_numpy(g("need_tokens")[step].astype(np.int32)).to(dev)
             seqs = torch.from_numpy(g("need_seqs")[step].astype(np.int32)).to(dev)
+            chunk = torch.from_numpy(g("chunkable")[step].astype(np.uint8)).to(dev)
             # perm indexes requests directly (ids are 0..n-1); pad-free: only queued ids appear in o
-            nsel, ran, granted = budget_prefix(torch.from_numpy(o).to(dev), need, seqs, B, S)
+            nsel, ran, granted = budget_prefix(torch.from_numpy(o).to(dev), need, seqs, B, S, chunkable=chunk)
             n = int(nsel.item())
             want = np.nonzero(g("ran")[step])[0]
             assert sorted(o[:n].tolist()) == want.tolist(), (fi, step)

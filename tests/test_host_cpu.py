@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ltr_abi_version() == 1
+    assert lib.ltr_abi_version() == _lib.ABI_VERSION
 
 
 def test_library_argument_errors_without_gpu():
@@ -41,11 +41,11 @@ def test_library_argument_errors_without_gpu():
     h = C.c_void_p()
     desc = _lib.ModelDesc(512, 100, 512, 2, 2, 128, 162, 1, 1, _lib.LTR_W_F16)     # head size != 64
     ptrs = (C.c_void_p * 31)()
-    assert lib.ltr_create(C.byref(desc), ptrs, 31, C.byref(h)) == -22
+    assert lib.ltr_create(C.byref(desc), ptrs, 31, None, C.byref(h)) == -22
     assert b"head size" in lib.ltr_last_error()
     desc = _lib.ModelDesc(512, 128, 512, 2, 2, 128, 162, 1, 1, _lib.LTR_W_F16)
-    assert lib.ltr_create(C.byref(desc), ptrs, 30, C.byref(h)) == -22               # wrong pointer count
-    assert lib.ltr_create(C.byref(desc), ptrs, 31, C.byref(h)) == -22               # NULL weights
+    assert lib.ltr_create(C.byref(desc), ptrs, 30, None, C.byref(h)) == -22               # wrong pointer count
+    assert lib.ltr_create(C.byref(desc), ptrs, 31, None, C.byref(h)) == -22               # NULL weights
     assert lib.ltr_workspace_bytes(None, _lib.LTR_WS_RANK, 8192, 0) >= 8192 * 12
     with pytest.raises(_lib.LtrError):
         _lib.check(-22, "x")

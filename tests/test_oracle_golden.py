@@ -33,21 +33,21 @@ def test_scorer_matches_reference(name):
         pytest.skip(f"{path} not generated")
     z = np.load(path, allow_pickle=False)
     spec = _spec_from(z)
-    if name in BIG_CASES and os.environ.get("LTR_BIG_ORACLE", "0") != "1":
-        # true-shape oracle runs take ~1 min of CPU each; covered on demand and by the GPU parity tests
-        pytest.skip("set LTR_BIG_ORACLE=1 for the true-shape oracle check")
     ckpt = seeded_checkpoint(spec, int(z["seed"]))
     orc = OracleOPTScorer(spec, ckpt)
     got = orc.score(z["ids"], z["cu_seqlens"])
+    # fp32 summation-order noise between two fp32 CPU implementations of a 12/24-layer stack is ~3e-6 at the
+    # true shapes (125m: 3.1e-6, 350m: 2.1e-6 measured) - an order of magnitude inside the 1e-4 parity bar
+    atol = 1e-5 if name in BIG_CASES else 2e-6
     if spec.num_labels == 1:
-        np.testing.assert_allclose(got, z["ref_score"], atol=2e-6, rtol=0)
-        np.testing.assert_allclose(got, z["hf_logits"][:, 0], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(got, z["ref_score"], atol=atol, rtol=0)
+        np.testing.assert_allclose(got, z["hf_logits"][:, 0], atol=atol, rtol=0)
     else:
         assert (got == z["ref_score"]).all()
         assert (got == z["hf_logits"].argmax(-1)).all()
     # batch-composition independence (SURVEY 7 'varlen batching'): packed == flat
-    packed = orc.score_packed(z["ids"], z["cu_seqlens"], max_tokens=256)
-    np.testing.assert_allclose(packed, got, atol=2e-6, rtol=0)
+    packed = orc.score_packed(z["ids"], z["cu_seqlens"], max_tokens=256 if name not in BIG_CASES else 2048)
+    np.testing.assert_allclose(packed, got, atol=atol, rtol=0)
 
 
 def test_scorer_empty():
@@ -107,21 +107,21 @@ def test_multi_step_schedule_replay():
         n = len(score)
         reqs = [rs.Req(str(i), float(score[i])) for i in range(n)]
         pri = np.zeros(n, np.int32); idle = np.zeros(n, np.int32); runs = np.zeros(n, np.int32)
+        concat = g("concat")
         for step in range(orders.shape[0]):
             want = orders[step][orders[step] >= 0]
-            members = sorted(want.tolist())            # who is queued this step
-            # the reference's concatenation order is not recorded; pri/score ties between
-            # queues are broken by it, so compare keys rather than ids where keys tie
+            # list(waiting)+list(running)+list(swapped) as the reference concatenated it (scheduler.py:985):
+            # the stable sort breaks (pri, score) ties by this order, so request IDS must match
+            members = concat[step][concat[step] >= 0].tolist()
+            assert sorted(members) == sorted(want.tolist())
             got = rs.opt_order([reqs[i] for i in members], starv, period)
-            key = lambda r: (r.pri, -r.aux_model_score)
-            assert [key(r) for r in got] == [key(reqs[i]) for i in want], f"case {fi} step {step}"
+            assert [int(r.request_id) for r in got] == want.tolist(), f"case {fi} step {step}"
             sub = np.array(members, np.int64)
             if len(sub):
                 p, i_, r_ = pri[sub].copy(), idle[sub].copy(), runs[sub].copy()
                 perm = rs.rank_step_np(score[sub], p, i_, r_, starv, period)
                 pri[sub], idle[sub], runs[sub] = p, i_, r_
-                assert [(int(pri[j]), -float(score[j])) for j in sub[perm]] == \
-                       [key(reqs[i]) for i in want]
+                assert sub[perm].tolist() == want.tolist(), f"case {fi} step {step} numpy"
             alive = np.nonzero(present[step])[0]
             rs.age_update([reqs[i] for i in alive], [reqs[i] for i in np.nonzero(ran[step])[0]])
             if len(alive):
@@ -173,9 +173,15 @@ def test_budget_walk_matches_reference_schedule():
         for step in range(g("orders").shape[0]):
             o = g("orders")[step]
             o = o[o >= 0]
-            nsel, granted = rs.budget_walk(g("need_tokens")[step][o], g("need_seqs")[step][o], B, S)
+            nsel, granted = rs.budget_walk(g("need_tokens")[step][o], g("need_seqs")[step][o], B, S,
+                                           g("chunkable")[step][o])
             assert set(o[:nsel].tolist()) == set(np.nonzero(g("ran")[step])[0].tolist()), (fi, step)
             assert granted == g("granted")[step][o[:nsel]].tolist(), (fi, step)
+    # the case the flag exists for: WAITING prompts with best_of = 2 (one sequence, new_seqs = 2) were granted chunks
+    g = lambda k: z[f"f3_{k}"]
+    multi = (g("need_seqs") > 1) & (g("granted") > 0)
+    assert (multi & (g("chunkable") == 1) & (g("granted") < g("need_tokens"))).any()
+    assert (multi & (g("chunkable") == 0)).any()
 
 
 def test_reserve_select_matches_reference_calls():

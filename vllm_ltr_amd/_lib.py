@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
@@ -21,7 +22,9 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
            "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
-           "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle")
+           "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
+           "ltr_status", "ltr_queue_step")
+ABI_VERSION = 2
 
 
 class LtrError(RuntimeError):
@@ -50,13 +53,21 @@ class ProfileStats(C.Structure):
 PROFILE_KINDS = ("gemm", "attn", "embed", "ln", "pool")
 
 _lib = None
+_load_lock = threading.Lock()
 
 
 def load() -> C.CDLL:
-    """Load libltr_hip.so (built in-tree by ``python -m vllm_ltr_amd.csrc.build``)."""
+    """Load libltr_hip.so (built in-tree by ``python -m vllm_ltr_amd.csrc.build``).  Thread-safe."""
     global _lib
     if _lib is not None:
         return _lib
+    with _load_lock:
+        if _lib is None:
+            _lib = _load()
+    return _lib
+
+
+def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise LtrError(f"{LIB_PATH} not found - build it with `python -m vllm_ltr_amd.csrc.build` "
                        "(there is no CPU fallback for the ranking path)")
@@ -69,7 +80,8 @@ def load() -> C.CDLL:
     vp, i32, i64, u32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_size_t
     lib.ltr_abi_version.restype = C.c_int
     lib.ltr_last_error.restype = C.c_char_p
-    lib.ltr_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp), i32, C.POINTER(vp)]
+    lib.ltr_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp), i32, vp, C.POINTER(vp)]
+    lib.ltr_status.argtypes = [vp, vp]
     lib.ltr_destroy.argtypes = [vp]
     lib.ltr_workspace_bytes.argtypes = [vp, i32, i64, i64]
     lib.ltr_workspace_bytes.restype = sz
@@ -78,9 +90,10 @@ def load() -> C.CDLL:
     lib.ltr_forward_hidden.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.ltr_embed_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ltr_pool_head.argtypes = [vp, vp, vp, i32, vp, vp, vp]
-    lib.ltr_rank_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, sz, vp]
-    lib.ltr_age_update.argtypes = [vp, vp, vp, vp, i32, vp]
-    lib.ltr_budget_prefix.argtypes = [vp, vp, vp, i32, i64, i64, vp, vp, vp, vp]
+    lib.ltr_rank_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, sz, vp]
+    lib.ltr_age_update.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+    lib.ltr_queue_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]
+    lib.ltr_budget_prefix.argtypes = [vp, vp, vp, vp, i32, i64, i64, vp, vp, vp, vp]
     lib.ltr_profile_enable.argtypes = [vp, i32]
     lib.ltr_profile_read.argtypes = [vp, C.POINTER(ProfileStats), i32]
     lib.ltr_reserve_select.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.c_int64, vp, vp, vp, vp]
@@ -92,7 +105,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version"):
             fn.restype = C.c_int
-    _lib = lib
+    if lib.ltr_abi_version() != ABI_VERSION:
+        raise LtrError(f"{LIB_PATH} has ABI version {lib.ltr_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
     return lib
 
 

@@ -1,20 +1,36 @@
-# Regenerates (on the GPU box, into gpurun_out/) the artefacts kept under profiles/: the PMC traffic of the GEMM
-# (first, because bench.py reads profiles/gemm_traffic.json for roofline.traffic), the default bench line and the
-# rocprofv3 kernel trace summary of the same command.
-set -x
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# Regenerates (on the GPU box, into gpurun_out/<tag>/) every artefact kept under profiles/ for the shipped kernels:
+#   1. PMC calibration of FETCH_SIZE / WRITE_SIZE on known-byte kernels (diag/pmc_calib.hip)
+#   2. PMC traffic of every kernel of the bench call  -> kernel_traffic.json (+ gemm_traffic.json, read by bench.py)
+#   3. SQ counters (MFMA busy, LDS bank conflicts, wave cycles) -> pmc_sq.txt
+#   4. the default bench line                          -> bench.json
+#   5. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv
+# usage: bash vllm_ltr_amd/csrc/diag/refresh_profiles.sh <tag>      (tag e.g. r02_v8); copy gpurun_out/<tag>/* to profiles/
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+set -x
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_w.log 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/vllm_ltr_amd/csrc/diag/pmc_calib.hip -o /tmp/pmc_calib || exit 1
+rocprofv3 --pmc FETCH_SIZE -d $O/calib_fetch -o f -- /tmp/pmc_calib > $O/calib_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/calib_write -o w -- /tmp/pmc_calib > $O/calib_w.log 2>&1
+BENCH="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- $BENCH > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- $BENCH > $O/pmc_w.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_sq -o s -- $BENCH > $O/pmc_s.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_l2 -o l -- $BENCH > $O/pmc_l.log 2>&1
 cd $R
-python profiles/make_gemm_traffic.py $(find gpurun_out/pmc_fetch -name "*.db" | head -1) $(find gpurun_out/pmc_write -name "*.db" | head -1)
-cp profiles/gemm_traffic.json gpurun_out/gemm_traffic_v4.json
-python bench.py > gpurun_out/bench_v4.json 2> gpurun_out/bench_v4.err
+db() { find $O/$1 -name "*.db" | head -1; }
+python profiles/make_traffic.py $(db pmc_fetch) $(db pmc_write) $(db calib_fetch) $(db calib_write) $O/kernel_traffic.json > $O/traffic.log 2>&1
+cp profiles/gemm_traffic.json $O/gemm_traffic.json
+python profiles/summarize_pmc.py $(db pmc_sq) $(db pmc_l2) > $O/pmc_sq.txt 2>&1
+python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_v4 -o v4 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_v4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1
 cd $R
-python profiles/summarize_rocpd.py $(find gpurun_out/prof_v4 -name "*.db" | head -1) gpurun_out/v4_kernel_stats.csv
-find gpurun_out -name "*.db" -delete
-tail -2 gpurun_out/bench_v4.json
+python profiles/summarize_rocpd.py $(db prof) $O/kernel_stats.csv > $O/kernel_stats.txt 2>&1
+find $O -name "*.db" -delete
+tail -1 $O/bench.json | cut -c1-600
+cat $O/kernel_stats.txt

@@ -40,6 +40,8 @@ struct ltr_model {
   ltr_model_desc d;
   std::vector<const void*> w;
   int chunk_tokens;
+  int device = 0;                  // ordinal of the device that owns the weights (made current around every launch)
+  int32_t* err_flag = nullptr;     // device word: bit 0 = a token id outside [0, vocab) was seen (ltr_status)
   bool prof_on = false;
   bool dbg_attn_valu = false;   // LTR_DEBUG_ATTN_VALU=1: f32 VALU attention inside the F16 mode (A/B for accuracy work)
   std::vector<ProfRec> prof;       // records in use
@@ -50,6 +52,7 @@ struct ltr_model {
   std::vector<const void*> wg;
   ~ltr_model() {
     if (packed) (void)hipFree(packed);
+    if (err_flag) (void)hipFree(err_flag);
     for (auto& r : prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (auto& e : prof_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
@@ -60,6 +63,17 @@ struct ltr_model {
 };
 
 namespace {
+
+// Makes the handle's device current for the duration of a call and restores the caller's device: kernel
+// launches and hipMalloc go to the CURRENT device, not to the device of their pointer arguments.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
 // tokens per pass: 3 x 65,536, so that every GEMM of a layer is a whole number of 512-workgroup rounds.
 // Measured on the 8k-queue call: 247 ms at 64k tokens per pass, 242 at 128k, 240 at 192k-384k, 242 for a
@@ -152,7 +166,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   {
     ProfScope p(m, LTR_K_EMBED, (double)Tc * (8.0 + (De + H) * wbytes + H * 4.0), s);
     rc = launch_embed_gather(wd, ids, cu_dev, N_total, Tc, t0, m->gw(LTR_WT_EMBED_TOKENS), De, d.vocab_size,
-                             m->gw(LTR_WT_EMBED_POS), H, d.pos_rows, ws.h, ws.a, s);
+                             m->gw(LTR_WT_EMBED_POS), H, d.pos_rows, ws.h, ws.a, m->err_flag, s);
   }
   if (rc) return rc;
   if (De != H) {   // h = project_in(tok) + pos : GEMM with the position rows as residual (in place)
@@ -240,9 +254,10 @@ int check_desc(const ltr_model_desc& d) {
     set_error("ltr_create: head size must be 64 (H=%d, heads=%d)", d.hidden_size, d.num_heads);
     return LTR_E_INVAL;
   }
-  if (d.hidden_size % 32 || d.ffn_dim % 32 || d.word_embed_proj_dim % 32 || d.hidden_size > 2048 ||
+  // F is the N of fc1 (the GEMM tiles N in 64-column wave strips) and the K of fc2 (32-wide slabs)
+  if (d.hidden_size % 32 || d.ffn_dim % 64 || d.word_embed_proj_dim % 32 || d.hidden_size > 2048 ||
       d.word_embed_proj_dim > 2048) {
-    set_error("ltr_create: H, F, De must be multiples of 32; H, De <= 2048");
+    set_error("ltr_create: H, De must be multiples of 32 (<= 2048) and F a multiple of 64");
     return LTR_E_INVAL;
   }
   if (d.weight_dtype != LTR_W_F32 && d.weight_dtype != LTR_W_F16) {
@@ -280,8 +295,10 @@ extern "C" {
 int ltr_abi_version(void) { return LTR_ABI_VERSION; }
 const char* ltr_last_error(void) { return ltr::g_err; }
 
-int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights, ltr_handle* out) {
+int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights, void* stream,
+               ltr_handle* out) {
   if (!desc || !weights || !out) { set_error("ltr_create: NULL argument"); return LTR_E_INVAL; }
+  hipStream_t cs = (hipStream_t)stream;
   int rc = check_desc(*desc);
   if (rc) return rc;
   const int want = LTR_WT_GLOBAL_COUNT + desc->num_layers * LTR_WL_COUNT;
@@ -301,6 +318,23 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
   m->d = *desc;
   m->w.assign(weights, weights + want);
   m->chunk_tokens = DEFAULT_CHUNK_TOKENS;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, weights[LTR_WT_EMBED_TOKENS]) != hipSuccess) {
+      (void)hipGetLastError();
+      delete m;
+      set_error("ltr_create: weight pointers must be device memory");
+      return LTR_E_INVAL;
+    }
+    m->device = attr.device;
+  }
+  DeviceGuard guard(m->device);
+  if (hipMalloc((void**)&m->err_flag, sizeof(int32_t)) != hipSuccess ||
+      hipMemsetAsync(m->err_flag, 0, sizeof(int32_t), cs) != hipSuccess) {
+    delete m;
+    set_error("ltr_create: cannot allocate the status word");
+    return LTR_E_NOMEM;
+  }
   { const char* e = getenv("LTR_DEBUG_ATTN_VALU"); m->dbg_attn_valu = e && e[0] == '1'; }
   m->wg = m->w;
   if (desc->weight_dtype == LTR_W_F16) {
@@ -327,19 +361,35 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
       size_t off = 0;
       for (auto& it : items) {
         void* dst = (char*)m->packed + off;
-        if ((rc = launch_pack_weight(m->w[it.idx], dst, (int)it.n, (int)it.k, nullptr))) { delete m; return rc; }
+        if ((rc = launch_pack_weight(m->w[it.idx], dst, (int)it.n, (int)it.k, cs))) { delete m; return rc; }
         m->wg[it.idx] = dst;
         off += (it.n * it.k * 2 + 255) / 256 * 256;
       }
-      if (hipStreamSynchronize(nullptr) != hipSuccess) { delete m; set_error("ltr_create: weight packing failed"); return LTR_E_HIP; }
     }
   }
+  if (hipStreamSynchronize(cs) != hipSuccess) { delete m; set_error("ltr_create: weight packing failed"); return LTR_E_HIP; }
   *out = m;
   return LTR_OK;
 }
 
 int ltr_destroy(ltr_handle h) {
-  delete h;
+  if (h) { DeviceGuard guard(h->device); delete h; }
+  return LTR_OK;
+}
+
+int ltr_status(ltr_handle h, void* stream) {
+  if (!h) { set_error("ltr_status: NULL handle"); return LTR_E_INVAL; }
+  DeviceGuard guard(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  int32_t flag = 0;
+  LTR_HIP_CHECK(hipMemcpyAsync(&flag, h->err_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
+  LTR_HIP_CHECK(hipStreamSynchronize(s));
+  if (flag) {
+    LTR_HIP_CHECK(hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), s));
+    set_error("ltr_score: a token id outside [0, %d) was fed to the embedding (F.embedding raises on it, "
+              "vocab_parallel_embedding.py:95-106); the scores of that call are invalid", h->d.vocab_size);
+    return LTR_E_INVAL;
+  }
   return LTR_OK;
 }
 
@@ -360,11 +410,12 @@ size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
 }
 
 static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, const int32_t* cu_host_in,
-                       int32_t N, int32_t T, int32_t n_layers, float* hidden_out, float* scores_out,
+                       int32_t N, int32_t T, int32_t max_len, int32_t n_layers, float* hidden_out, float* scores_out,
                        float* logits_out, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (!h) { set_error("ltr_score: NULL handle"); return LTR_E_INVAL; }
   if (N < 0 || T < 0) { set_error("ltr_score: negative size"); return LTR_E_INVAL; }
   if (N == 0) return LTR_OK;
+  DeviceGuard guard(h->device);
   if (!token_ids || !cu_seqlens || !workspace) { set_error("ltr_score: NULL pointer"); return LTR_E_INVAL; }
   std::vector<int32_t> tmp;
   const int32_t* cu = nullptr;
@@ -373,6 +424,13 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
   if (cu[0] != 0 || cu[N] != T) { set_error("ltr_score: cu_seqlens[0]=%d cu_seqlens[N]=%d, T=%d", cu[0], cu[N], T); return LTR_E_INVAL; }
   const ltr_model_desc& d = h->d;
   const int max_pos = d.pos_rows - 2;
+  if (max_len > 0) {
+    for (int r = 0; r < N; ++r)
+      if (cu[r + 1] - cu[r] > max_len) {
+        set_error("ltr_score: request %d has %d tokens > max_len %d", r, cu[r + 1] - cu[r], max_len);
+        return LTR_E_INVAL;
+      }
+  }
   // chunk budget from the workspace actually provided
   int64_t Tc_cap = chunk_cap(h) < T ? chunk_cap(h) : T;
   while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr).bytes > ws_bytes) Tc_cap /= 2;
@@ -420,19 +478,17 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
 int ltr_score(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, const int32_t* cu_seqlens_host,
               int32_t N, int32_t T, int32_t max_len, float* scores_out, float* logits_out, void* workspace,
               size_t ws_bytes, void* stream) {
-  (void)max_len;
   if (N > 0 && !scores_out) { set_error("ltr_score: scores_out is NULL"); return LTR_E_INVAL; }
-  return run_forward(h, token_ids, cu_seqlens, cu_seqlens_host, N, T, -1, nullptr, scores_out, logits_out, workspace,
-                     ws_bytes, (hipStream_t)stream);
+  return run_forward(h, token_ids, cu_seqlens, cu_seqlens_host, N, T, max_len, -1, nullptr, scores_out, logits_out,
+                     workspace, ws_bytes, (hipStream_t)stream);
 }
 
 int ltr_forward_hidden(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
                        const int32_t* cu_seqlens_host, int32_t N, int32_t T, int32_t max_len, int32_t n_layers,
                        float* hidden_out, void* workspace, size_t ws_bytes, void* stream) {
-  (void)max_len;
   if (N > 0 && !hidden_out) { set_error("ltr_forward_hidden: hidden_out is NULL"); return LTR_E_INVAL; }
-  return run_forward(h, token_ids, cu_seqlens, cu_seqlens_host, N, T, n_layers, hidden_out, nullptr, nullptr, workspace,
-                     ws_bytes, (hipStream_t)stream);
+  return run_forward(h, token_ids, cu_seqlens, cu_seqlens_host, N, T, max_len, n_layers, hidden_out, nullptr, nullptr,
+                     workspace, ws_bytes, (hipStream_t)stream);
 }
 
 int ltr_embed_gather(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, int32_t N, int32_t T,
@@ -443,36 +499,53 @@ int ltr_embed_gather(ltr_handle h, const int64_t* token_ids, const int32_t* cu_s
   if (proj && !tok_out) { set_error("ltr_embed_gather: tok_out required when De != H"); return LTR_E_INVAL; }
   AOp tok{tok_out, nullptr};
   if (proj && d.weight_dtype == LTR_W_F16) tok.lo = (char*)tok_out + (size_t)T * d.word_embed_proj_dim * 2;
+  DeviceGuard guard(h->device);
   return launch_embed_gather(d.weight_dtype, token_ids, cu_seqlens, N, T, 0, h->gw(LTR_WT_EMBED_TOKENS),
                              d.word_embed_proj_dim, d.vocab_size, h->gw(LTR_WT_EMBED_POS), d.hidden_size, d.pos_rows,
-                             hidden_out, tok, (hipStream_t)stream);
+                             hidden_out, tok, h->err_flag, (hipStream_t)stream);
 }
 
 int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, int32_t N, float* scores_out,
                   float* logits_out, void* stream) {
   if (!h || !hidden || !cu_seqlens || !scores_out) { set_error("ltr_pool_head: NULL argument"); return LTR_E_INVAL; }
   const ltr_model_desc& d = h->d;
+  DeviceGuard guard(h->device);
   return launch_pool_head(d.weight_dtype, hidden, cu_seqlens, 0, N, d.hidden_size, d.word_embed_proj_dim, d.num_labels,
                           (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
                           d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
                           h->gw(LTR_WT_SCORE), scores_out, logits_out, (hipStream_t)stream);
 }
 
-int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak, int32_t N,
-                  int32_t starv, int32_t period, uint32_t flags, int32_t* perm_out, void* workspace, size_t ws_bytes,
-                  void* stream) {
+int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                  const int32_t* members, int32_t N, int32_t starv, int32_t period, uint32_t flags, int32_t* perm_out,
+                  void* workspace, size_t ws_bytes, void* stream) {
   if (N < 0) { set_error("ltr_rank_step: negative N"); return LTR_E_INVAL; }
   if (N == 0) return LTR_OK;
-  if (!scores || !perm_out || !workspace) { set_error("ltr_rank_step: NULL argument"); return LTR_E_INVAL; }
-  return launch_rank_step(scores, pri, idle, runs, tiebreak, N, starv, period, flags, perm_out, workspace, ws_bytes,
-                          (hipStream_t)stream);
+  if (!scores || !perm_out) { set_error("ltr_rank_step: NULL argument"); return LTR_E_INVAL; }
+  return launch_rank_step(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, workspace,
+                          ws_bytes, (hipStream_t)stream);
 }
 
-int ltr_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int32_t N, void* stream) {
-  if (N < 0) { set_error("ltr_age_update: negative N"); return LTR_E_INVAL; }
+int ltr_age_update(const uint8_t* ran, const int32_t* ran_slots, int32_t n_ran, int32_t* pri, int32_t* idle,
+                   int32_t* runs, const int32_t* members, int32_t N, void* stream) {
+  if (N < 0 || n_ran < 0) { set_error("ltr_age_update: negative size"); return LTR_E_INVAL; }
   if (N == 0) return LTR_OK;
-  if (!ran || !pri || !idle || !runs) { set_error("ltr_age_update: NULL argument"); return LTR_E_INVAL; }
-  return launch_age_update(ran, pri, idle, runs, N, (hipStream_t)stream);
+  if ((!ran && n_ran > 0 && !ran_slots) || !pri || !idle || !runs) { set_error("ltr_age_update: NULL argument"); return LTR_E_INVAL; }
+  return launch_age_update(ran, ran_slots, n_ran, pri, idle, runs, members, N, (hipStream_t)stream);
+}
+
+int ltr_queue_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                   const int32_t* members, int32_t N, int32_t starv, int32_t period, uint32_t flags,
+                   const int32_t* new_tokens, const int32_t* new_seqs, const uint8_t* chunkable, int64_t token_budget,
+                   int64_t max_num_seqs, int32_t* perm_out, int32_t* n_selected_out, uint8_t* ran_out,
+                   int32_t* granted_out, void* workspace, size_t ws_bytes, void* stream) {
+  if (N < 0 || !n_selected_out || (N > 0 && (!scores || !perm_out || !new_tokens || !new_seqs))) {
+    set_error("ltr_queue_step: bad argument");
+    return LTR_E_INVAL;
+  }
+  return launch_queue_step(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, new_tokens, new_seqs,
+                           chunkable, token_budget, max_num_seqs, perm_out, n_selected_out, ran_out, granted_out,
+                           workspace, ws_bytes, (hipStream_t)stream);
 }
 
 int ltr_profile_enable(ltr_handle h, int32_t on) {
@@ -483,6 +556,7 @@ int ltr_profile_enable(ltr_handle h, int32_t on) {
 
 int ltr_profile_read(ltr_handle h, ltr_profile_stats* out, int32_t reset) {
   if (!h || !out) { set_error("ltr_profile_read: NULL argument"); return LTR_E_INVAL; }
+  DeviceGuard guard(h->device);
   memset(out, 0, sizeof(*out));
   for (auto& r : h->prof) {
     LTR_HIP_CHECK(hipEventSynchronize(r.stop));
@@ -499,15 +573,15 @@ int ltr_profile_read(ltr_handle h, ltr_profile_stats* out, int32_t reset) {
   return LTR_OK;
 }
 
-int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int32_t N,
-                      int64_t token_budget, int64_t max_num_seqs, int32_t* n_selected_out, uint8_t* ran_out,
-                      int32_t* granted_out, void* stream) {
+int ltr_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs,
+                      const uint8_t* chunkable, int32_t N, int64_t token_budget, int64_t max_num_seqs,
+                      int32_t* n_selected_out, uint8_t* ran_out, int32_t* granted_out, void* stream) {
   if (N < 0 || !n_selected_out || (N > 0 && (!perm || !new_tokens || !new_seqs))) {
     set_error("ltr_budget_prefix: bad argument");
     return LTR_E_INVAL;
   }
-  return launch_budget_prefix(perm, new_tokens, new_seqs, N, token_budget, max_num_seqs, n_selected_out, ran_out,
-                              granted_out, (hipStream_t)stream);
+  return launch_budget_prefix(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_num_seqs, n_selected_out,
+                              ran_out, granted_out, (hipStream_t)stream);
 }
 
 int ltr_reserve_select(const int32_t* perm, const int32_t* n_selected, const uint8_t* state, const int32_t* phys,

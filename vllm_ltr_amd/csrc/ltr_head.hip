@@ -153,6 +153,10 @@ int ltr_head_score(ltr_head_handle h, const float* hidden, const int32_t* row_in
   if (!m || !hidden || !scores_out) { set_error("ltr_head_score: NULL argument"); return LTR_E_INVAL; }
   const size_t lds = (size_t)2 * m->maxw * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
+  if (lds > 48 * 1024) {   // up to 64 KiB at HD_MAXW: above the default dynamic-LDS limit of a launch
+    const void* fn = m->d.weight_dtype == LTR_W_F16 ? (const void*)ltr_head_kernel<__half> : (const void*)ltr_head_kernel<float>;
+    LTR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   if (m->d.weight_dtype == LTR_W_F16)
     ltr_head_kernel<__half><<<N, HD_THREADS, lds, s>>>(hidden, row_index, m->d.n_features, m->ln_w, m->ln_b, m->L,
                                                        m->d.activation, m->d.output_activation, scores_out);

@@ -76,7 +76,7 @@ int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_re
 
 int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N, int T, int tok_off,
                         const void* tok_table, int De, int vocab, const void* pos_table, int H, int pos_rows,
-                        float* hidden_out, AOp tok_out /*only if De != H*/, hipStream_t s);
+                        float* hidden_out, AOp tok_out /*only if De != H*/, int32_t* err_flag /*nullable*/, hipStream_t s);
 
 // varlen causal attention over qkv [T, 3H] (q | k | v, heads of 64; f32, or fp16 hi|lo planes
 // in the F16 mode), writes operand [T, H]
@@ -91,12 +91,18 @@ int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu /*nullpt
 
 size_t rank_workspace_bytes(int64_t N);
 int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
-                     int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws, size_t ws_bytes,
-                     hipStream_t s);
-int launch_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int N, hipStream_t s);
-int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int N,
-                         int64_t token_budget, int64_t max_seqs, int32_t* n_sel, uint8_t* ran, int32_t* granted,
-                         hipStream_t s);
+                     const int32_t* members, int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws,
+                     size_t ws_bytes, hipStream_t s);
+int launch_queue_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                      const int32_t* members, int N, int starv, int period, uint32_t flags, const int32_t* new_tokens,
+                      const int32_t* new_seqs, const uint8_t* chunkable, int64_t token_budget, int64_t max_seqs,
+                      int32_t* perm_out, int32_t* n_sel, uint8_t* ran, int32_t* granted, void* ws, size_t ws_bytes,
+                      hipStream_t s);
+int launch_age_update(const uint8_t* ran, const int32_t* ran_slots, int n_ran, int32_t* pri, int32_t* idle,
+                      int32_t* runs, const int32_t* members, int N, hipStream_t s);
+int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs,
+                         const uint8_t* chunkable, int N, int64_t token_budget, int64_t max_seqs, int32_t* n_sel,
+                         uint8_t* ran, int32_t* granted, hipStream_t s);
 int launch_reserve_select(const int32_t* perm, const int32_t* n_sel, const uint8_t* state, const int32_t* phys,
                           const int32_t* logical, const int32_t* nrun, const int32_t* nswap, const int32_t* new_seqs,
                           int N, int64_t need_in, uint8_t* action, int32_t* n_exec, int32_t* blocks_required,

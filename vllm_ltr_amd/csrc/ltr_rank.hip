@@ -10,9 +10,20 @@
 // plain sort of unique 64-bit keys and rank(i) = #{j : key_j < key_i} is a permutation.
 // For queue sizes on this path (1k..64k) a rank-by-counting sort fills all 256 CUs with
 // independent work and needs no inter-workgroup hand-off: each workgroup owns 64 keys,
-// streams a slice of the key array through LDS (coalesced 8-byte loads, broadcast
-// ds_read_b64), and counts.  Slices of j are spread over gridDim.y workgroups and merged
-// with one atomicAdd per key, so even an 8k queue launches >= 512 workgroups.
+// streams the key array through LDS (broadcast ds_read_b64), and counts.
+//
+// Device-resident queue state: score / pri / idle / runs live in SLOT arrays that persist
+// across scheduler steps; a step hands over `members` = the slot of every request in the order
+// list(waiting)+list(running)+list(swapped) (scheduler.py:985,996).  Position i in `members` is the stable
+// sort's tiebreak and what perm_out refers to; members == nullptr means slot == position.
+//
+// Launch count of a steady step (nothing new to score) at N <= RK_BUCKET_MIN:
+//   ltr_rank_step  = rank_fused_kernel (read-only: keys are rebuilt from the state on the fly while the
+//                    chunks are staged, counted, and perm is written directly) + rank_apply_kernel
+//                    (promote/demote in place)                                              2 launches
+//   ltr_queue_step = rank_fused_kernel + queue_tail_kernel (budget-walk scan, ran marking,
+//                    promote/demote and aging in ONE single-workgroup launch)               2 launches
+// (round 1: prepare, count, scatter, budget_prefix, budget_mark, age_update = 6 launches).
 #include "ltr_internal.h"
 
 namespace ltr {
@@ -29,57 +40,124 @@ __device__ __forceinline__ uint32_t float_order_bits(float x) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float -> ascending u32
 }
 
+// scheduler.py:986-993 on one request's counters (by value); returns the effective pri
+__device__ __forceinline__ int promote_demote(int p, int& id, int& rn, int starv, int period) {
+  if (id >= starv) { p = -1; id = 0; rn = period; }
+  else if (p == -1 && rn <= 0) p = 0;
+  return p;
+}
+
+__device__ __forceinline__ uint64_t make_key(float sc, int p, uint32_t tb, uint32_t flags) {
+  const float k = (flags & LTR_RANK_ASCENDING) ? sc : -sc;
+  uint64_t pbit = 0;
+  if (flags & LTR_RANK_USE_PRI) pbit = (p < 0) ? 0ull : 1ull;   // pri in {-1, 0}: -1 first
+  return (pbit << 63) | ((uint64_t)float_order_bits(k) << 31) | (uint64_t)(tb & 0x7fffffffu);
+}
+
+// key of position i from the (unmodified) state: promote/demote is evaluated by value
+__device__ __forceinline__ uint64_t key_of(const float* __restrict__ score, const int32_t* __restrict__ pri,
+                                           const int32_t* __restrict__ idle, const int32_t* __restrict__ runs,
+                                           const uint32_t* __restrict__ tiebreak, const int32_t* __restrict__ members,
+                                           int i, int starv, int period, uint32_t flags) {
+  const int sl = members ? members[i] : i;
+  int p = 0;
+  if (flags & LTR_RANK_USE_PRI) {
+    p = pri[sl];
+    if (starv != -1) { int id = idle[sl], rn = runs[sl]; p = promote_demote(p, id, rn, starv, period); }
+  }
+  return make_key(score[sl], p, tiebreak ? tiebreak[i] : (uint32_t)i, flags);
+}
+
+// One launch for the whole ranking of a queue of N <= RK_BUCKET_MIN requests: a workgroup owns 64 positions,
+// rebuilds the keys of every chunk of 1024 positions from the state while staging them into LDS (4 coalesced
+// loads per key instead of one 8-byte load: ~N/64 x N x 16 B of L2 reads in total, 17 MB at 8k), counts, and
+// writes perm directly.  The state is only READ here, so workgroups never see each other's updates.
+__global__ void __launch_bounds__(256) rank_fused_kernel(
+    const float* __restrict__ score, const int32_t* __restrict__ pri, const int32_t* __restrict__ idle,
+    const int32_t* __restrict__ runs, const uint32_t* __restrict__ tiebreak, const int32_t* __restrict__ members, int N,
+    int starv, int period, uint32_t flags, int32_t* __restrict__ perm) {
+  __shared__ uint64_t skeys[1024];
+  __shared__ int32_t spart[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const uint64_t ki = (i < N) ? key_of(score, pri, idle, runs, tiebreak, members, i, starv, period, flags) : 0ull;
+  int cnt = 0;
+  for (int j0 = 0; j0 < N; j0 += 1024) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + r * 256 + threadIdx.x;
+      skeys[r * 256 + threadIdx.x] = (j < N) ? key_of(score, pri, idle, runs, tiebreak, members, j, starv, period, flags) : ~0ull;
+    }
+    __syncthreads();
+    const uint64_t* sk = skeys + wave * 256;
+#pragma unroll 16
+    for (int jj = 0; jj < 256; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
+  }
+  spart[threadIdx.x] = cnt;
+  __syncthreads();
+  if (wave == 0 && i < N) perm[spart[lane] + spart[64 + lane] + spart[128 + lane] + spart[192 + lane]] = i;
+}
+
+// promote/demote in place (scheduler.py:986-993), after rank_fused_kernel read the old state
+__global__ void __launch_bounds__(256) rank_apply_kernel(int32_t* __restrict__ pri, int32_t* __restrict__ idle,
+                                                         int32_t* __restrict__ runs, const int32_t* __restrict__ members,
+                                                         int N, int starv, int period) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int sl = members ? members[i] : i;
+  const int p0 = pri[sl], id0 = idle[sl], rn0 = runs[sl];
+  int id = id0, rn = rn0;
+  const int p = promote_demote(p0, id, rn, starv, period);
+  if (p != p0) pri[sl] = p;
+  if (id != id0) idle[sl] = id;
+  if (rn != rn0) runs[sl] = rn;
+}
+
 // scheduler.py:986-993 + key build.  Also zeroes the rank accumulators.
 __global__ void __launch_bounds__(256) rank_prepare_kernel(
     const float* __restrict__ score, int32_t* __restrict__ pri, int32_t* __restrict__ idle,
-    int32_t* __restrict__ runs, const uint32_t* __restrict__ tiebreak, int N, int starv, int period,
-    uint32_t flags, uint64_t* __restrict__ keys, int32_t* __restrict__ rank) {
+    int32_t* __restrict__ runs, const uint32_t* __restrict__ tiebreak, const int32_t* __restrict__ members, int N,
+    int starv, int period, uint32_t flags, uint64_t* __restrict__ keys, int32_t* __restrict__ rank) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  const int sl = members ? members[i] : i;
   int p = 0;
   if (pri != nullptr) {
-    p = pri[i];
+    p = pri[sl];
     if (starv != -1) {
-      int id = idle[i];
+      int id = idle[sl];
       if (id >= starv) {
         p = -1;
-        pri[i] = -1;
-        idle[i] = 0;
-        runs[i] = period;
-      } else if (p == -1 && runs[i] <= 0) {
+        pri[sl] = -1;
+        idle[sl] = 0;
+        runs[sl] = period;
+      } else if (p == -1 && runs[sl] <= 0) {
         p = 0;
-        pri[i] = 0;
+        pri[sl] = 0;
       }
     }
   }
-  float sc = score[i];
-  float k = (flags & LTR_RANK_ASCENDING) ? sc : -sc;
-  uint64_t pbit = 0;
-  if (flags & LTR_RANK_USE_PRI) pbit = (p < 0) ? 0ull : 1ull;   // pri in {-1, 0}: -1 first
-  uint32_t tb = tiebreak ? tiebreak[i] : (uint32_t)i;
-  keys[i] = (pbit << 63) | ((uint64_t)float_order_bits(k) << 31) | (uint64_t)(tb & 0x7fffffffu);
+  keys[i] = make_key(score[sl], p, tiebreak ? tiebreak[i] : (uint32_t)i, flags);
   rank[i] = 0;
 }
 
-template <bool DIRECT>
+// rank of every key among keys[0..N) by counting (the sorted sample of the bucketed path): perm[rank] = i
 __global__ void __launch_bounds__(RK_THREADS) rank_count_kernel(
-    const uint64_t* __restrict__ keys, int N, int j_per_block, int32_t* __restrict__ rank,
-    int32_t* __restrict__ perm) {
+    const uint64_t* __restrict__ keys, int N, int32_t* __restrict__ perm) {
   __shared__ uint64_t skeys[RK_CHUNK];
   __shared__ int32_t spart[RK_THREADS];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = blockIdx.x * RK_ITILE + lane;
   const uint64_t ki = (i < N) ? keys[i] : 0ull;
-  const int jb = blockIdx.y * j_per_block;
-  const int je = min(N, jb + j_per_block);
   int cnt = 0;
-  for (int j0 = jb; j0 < je; j0 += RK_CHUNK) {
+  for (int j0 = 0; j0 < N; j0 += RK_CHUNK) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RK_CHUNK / RK_THREADS; ++r) {
       int j = j0 + r * RK_THREADS + threadIdx.x;
-      skeys[r * RK_THREADS + threadIdx.x] = (j < je) ? keys[j] : ~0ull;  // pad: never < ki
+      skeys[r * RK_THREADS + threadIdx.x] = (j < N) ? keys[j] : ~0ull;  // pad: never < ki
     }
     __syncthreads();
     const uint64_t* sk = skeys + wave * (RK_CHUNK / 4);
@@ -88,17 +166,7 @@ __global__ void __launch_bounds__(RK_THREADS) rank_count_kernel(
   }
   spart[threadIdx.x] = cnt;
   __syncthreads();
-  if (wave == 0 && i < N) {
-    int total = spart[lane] + spart[64 + lane] + spart[128 + lane] + spart[192 + lane];
-    if (DIRECT) perm[total] = i;
-    else atomicAdd(&rank[i], total);
-  }
-}
-
-__global__ void __launch_bounds__(256) rank_scatter_kernel(const int32_t* __restrict__ rank, int N,
-                                                           int32_t* __restrict__ perm) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) perm[rank[i]] = i;
+  if (wave == 0 && i < N) perm[spart[lane] + spart[64 + lane] + spart[128 + lane] + spart[192 + lane]] = i;
 }
 
 // ---- large queues (N > RK_BUCKET_MIN): sample-sort front end ---------------------------------
@@ -108,7 +176,7 @@ __global__ void __launch_bounds__(256) rank_scatter_kernel(const int32_t* __rest
 // the counting rank runs inside each bucket only: O(N * N/256).  The order of keys inside a bucket
 // after the atomic scatter is arbitrary, which is harmless: the in-bucket rank depends on the keys
 // alone, so the permutation is the same bit-exact stable order.
-constexpr int RK_BUCKET_MIN = 12288;   // measured crossover: 8k 45 us (counting) vs 62 us; 16k 69 vs 59 us
+constexpr int RK_BUCKET_MIN = 12288;   // measured crossover (round 1, 3-launch counting rank): 8k 45 us vs 62 us; 16k 69 vs 59 us
 constexpr int RK_NBUCKET = 256;
 constexpr int RK_NSAMPLE = 2048;
 
@@ -224,17 +292,30 @@ __global__ void __launch_bounds__(256) rank_in_bucket_kernel(const uint64_t* __r
   }
 }
 
-// scheduler.py:1358-1365
+// scheduler.py:1358-1365.  `ran` is a u8 flag per POSITION, or - when ran == nullptr - membership of the
+// request's SLOT in the ascending list ran_slots[n_ran] (what a scheduler hands over: the <= max_num_seqs
+// requests it scheduled this step; binary search instead of an N-byte mask upload).
 __global__ void __launch_bounds__(256) age_update_kernel(const uint8_t* __restrict__ ran,
+                                                         const int32_t* __restrict__ ran_slots, int n_ran,
                                                          int32_t* __restrict__ pri, int32_t* __restrict__ idle,
-                                                         int32_t* __restrict__ runs, int N) {
+                                                         int32_t* __restrict__ runs,
+                                                         const int32_t* __restrict__ members, int N) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  if (ran[i]) {
-    if (pri[i] == -1) runs[i] -= 1;
-    idle[i] = 0;
+  const int sl = members ? members[i] : i;
+  bool r;
+  if (ran != nullptr) {
+    r = ran[i] != 0;
   } else {
-    idle[i] += 1;
+    int lo = 0, hi = n_ran;                    // first index with ran_slots[idx] >= sl
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ran_slots[mid] < sl) lo = mid + 1; else hi = mid; }
+    r = lo < n_ran && ran_slots[lo] == sl;
+  }
+  if (r) {
+    if (pri[sl] == -1) runs[sl] -= 1;
+    idle[sl] = 0;
+  } else {
+    idle[sl] += 1;
   }
 }
 
@@ -243,50 +324,95 @@ __global__ void __launch_bounds__(256) age_update_kernel(const uint8_t* __restri
 // enable_chunking = True, :1128) a single-sequence request is granted
 // min(need, remaining_token_budget), so the walk selects request k (in ranked order) iff
 // for every j <= k:  need_j > 0, sum_{i<j} need_i < token_budget and
-// sum_{i<=j} seqs_i <= max_num_seqs; it breaks at the first k that fails.  Groups with
-// more than one sequence are not chunked and must fit whole.
+// sum_{i<=j} seqs_i <= max_num_seqs; it breaks at the first k that fails.  A group is chunked iff it
+// has exactly ONE sequence in the walked status (:1884) - `chunkable`, which is not `seqs == 1`: a
+// WAITING prompt with best_of > 1 has one sequence and new_seqs = best_of (sequence.py:500-504).
+// Groups that are not chunkable must fit whole.
 // Single workgroup, blocked scan over the ranked order.
 constexpr int BP_THREADS = 1024;
-__global__ void __launch_bounds__(BP_THREADS) budget_prefix_kernel(
-    const int32_t* __restrict__ perm, const int32_t* __restrict__ new_tokens,
-    const int32_t* __restrict__ new_seqs, int N, long long token_budget, long long max_seqs,
-    int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran, int32_t* __restrict__ granted) {
-  __shared__ long long s_tok[BP_THREADS / 64], s_seq[BP_THREADS / 64];
-  __shared__ long long carry_tok, carry_seq;
-  __shared__ int first_bad;
+struct BudgetShared {
+  long long tok[BP_THREADS / 64], seq[BP_THREADS / 64];
+  long long carry_tok, carry_seq;
+  int first_bad;
+};
+// blocked scan over the ranked order by one workgroup of BP_THREADS threads; returns the number of
+// selected requests (uniform).  granted[] is written for the scanned positions only.
+__device__ int budget_scan(const int32_t* __restrict__ perm, const int32_t* __restrict__ new_tokens,
+                           const int32_t* __restrict__ new_seqs, const uint8_t* __restrict__ chunkable, int N,
+                           long long token_budget, long long max_seqs, int32_t* __restrict__ granted, BudgetShared& sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { carry_tok = 0; carry_seq = 0; first_bad = N; }
+  if (tid == 0) { sh.carry_tok = 0; sh.carry_seq = 0; sh.first_bad = N; }
   __syncthreads();
   for (int base = 0; base < N; base += BP_THREADS) {
     int k = base + tid;
     long long t = 0, q = 0;
     int nt = 0, nq = 0, r = 0;
-    if (k < N) { r = perm[k]; nt = new_tokens[r]; nq = new_seqs[r]; t = nt; q = nq; }
+    bool chunk = true;
+    if (k < N) {
+      r = perm[k]; nt = new_tokens[r]; nq = new_seqs[r]; t = nt; q = nq;
+      chunk = chunkable ? chunkable[r] != 0 : nq <= 1;
+    }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
       long long tt = __shfl_up(t, o, 64), qq = __shfl_up(q, o, 64);
       if (lane >= o) { t += tt; q += qq; }
     }
-    if (lane == 63) { s_tok[wave] = t; s_seq[wave] = q; }
+    if (lane == 63) { sh.tok[wave] = t; sh.seq[wave] = q; }
     __syncthreads();
-    long long ot = carry_tok, oq = carry_seq;
-    for (int w = 0; w < wave; ++w) { ot += s_tok[w]; oq += s_seq[w]; }
+    long long ot = sh.carry_tok, oq = sh.carry_seq;
+    for (int w = 0; w < wave; ++w) { ot += sh.tok[w]; oq += sh.seq[w]; }
     t += ot; q += oq;
     const long long before = t - nt;
     bool bad = (k < N) && (nt == 0 || before >= token_budget || q > max_seqs ||
-                           (nq > 1 && t > token_budget));
-    if (bad) atomicMin(&first_bad, k);
+                           (!chunk && t > token_budget));
+    if (bad) atomicMin(&sh.first_bad, k);
     if (k < N && granted != nullptr) {
       long long g = token_budget - before;
-      granted[r] = (int)(g < nt ? (g > 0 ? g : 0) : nt);
+      granted[r] = (int)(chunk && g < nt ? (g > 0 ? g : 0) : nt);
     }
     __syncthreads();
-    if (tid == BP_THREADS - 1) { carry_tok = t; carry_seq = q; }
+    if (tid == BP_THREADS - 1) { sh.carry_tok = t; sh.carry_seq = q; }
     __syncthreads();
-    if (first_bad < N) break;   // uniform: read after the barrier
+    if (sh.first_bad < N) break;   // uniform: read after the barrier
   }
   __syncthreads();
-  if (tid == 0) *n_sel = first_bad;
+  return sh.first_bad;
+}
+
+__global__ void __launch_bounds__(BP_THREADS) budget_prefix_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ new_tokens,
+    const int32_t* __restrict__ new_seqs, const uint8_t* __restrict__ chunkable, int N, long long token_budget,
+    long long max_seqs, int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran, int32_t* __restrict__ granted) {
+  __shared__ BudgetShared sh;
+  const int nsel = budget_scan(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_seqs, granted, sh);
+  if (threadIdx.x == 0) *n_sel = nsel;
+}
+
+// The rest of a steady scheduler step in ONE single-workgroup launch, after the rank: budget-walk scan
+// (scheduler.py:1137-1211), ran marking, promote/demote write-back (:986-993; the rank kernel only read the
+// state) and aging (:1358-1365) of every queued request.  8k requests = 8 per thread.
+__global__ void __launch_bounds__(BP_THREADS) queue_tail_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ members, const int32_t* __restrict__ new_tokens,
+    const int32_t* __restrict__ new_seqs, const uint8_t* __restrict__ chunkable, int N, long long token_budget,
+    long long max_seqs, int starv, int period, int apply_promote, int32_t* __restrict__ pri,
+    int32_t* __restrict__ idle, int32_t* __restrict__ runs, int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran,
+    int32_t* __restrict__ granted) {
+  __shared__ BudgetShared sh;
+  const int nsel = budget_scan(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_seqs, granted, sh);
+  if (threadIdx.x == 0) *n_sel = nsel;
+  for (int k = threadIdx.x; k < N; k += BP_THREADS) {
+    const int r = perm[k];
+    const int sl = members ? members[r] : r;
+    const bool rn_ = k < nsel;
+    if (ran != nullptr) ran[r] = rn_ ? 1 : 0;
+    if (granted != nullptr && !rn_) granted[r] = 0;
+    if (pri != nullptr) {
+      int p = pri[sl], id = idle[sl], ru = runs[sl];
+      if (apply_promote && starv != -1) p = promote_demote(p, id, ru, starv, period);
+      if (rn_) { if (p == -1) ru -= 1; id = 0; } else { id += 1; }
+      pri[sl] = p; idle[sl] = id; runs[sl] = ru;
+    }
+  }
 }
 
 // second phase on the whole chip: ran[perm[k]] = k < n_sel, granted = 0 past the selection
@@ -396,14 +522,9 @@ size_t rank_workspace_bytes(int64_t N) {
   return b;
 }
 
-int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
-                     int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws, size_t ws_bytes,
-                     hipStream_t s) {
-  if (N == 0) return LTR_OK;
-  if (ws_bytes < rank_workspace_bytes(N)) {
-    set_error("ltr_rank_step: workspace %zu < %zu", ws_bytes, rank_workspace_bytes(N));
-    return LTR_E_NOMEM;
-  }
+namespace {
+
+int check_rank_args(const int32_t* pri, const int32_t* idle, const int32_t* runs, int starv, uint32_t& flags) {
   if (starv != -1) flags |= LTR_RANK_USE_PRI;           // scheduler.py:996 vs :998
   if ((flags & LTR_RANK_USE_PRI) && pri == nullptr) {
     set_error("ltr_rank_step: pri is NULL but the key uses it");
@@ -413,70 +534,111 @@ int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* 
     set_error("ltr_rank_step: starvation control needs idle and runs");
     return LTR_E_INVAL;
   }
+  return LTR_OK;
+}
+
+// N > RK_BUCKET_MIN: promote/demote in place + keys, sample-sort front end, counting rank inside the buckets
+int launch_rank_bucketed(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                         const int32_t* members, int N, int starv, int period, uint32_t flags, int32_t* perm_out,
+                         void* ws, size_t ws_bytes, hipStream_t s) {
+  if (ws == nullptr || ws_bytes < rank_workspace_bytes(N)) {
+    set_error("ltr_rank_step: workspace %zu < %zu", ws_bytes, rank_workspace_bytes(N));
+    return LTR_E_NOMEM;
+  }
   int64_t n64 = ((int64_t)N + 63) / 64 * 64;
   uint64_t* keys = (uint64_t*)ws;
   int32_t* rank = (int32_t*)((char*)ws + n64 * sizeof(uint64_t));
   rank_prepare_kernel<<<(N + 255) / 256, 256, 0, s>>>(scores, (flags & LTR_RANK_USE_PRI) ? pri : nullptr, idle,
-                                                      runs, tiebreak, N, starv, period, flags, keys, rank);
+                                                      runs, tiebreak, members, N, starv, period, flags, keys, rank);
   LTR_LAUNCH_CHECK();
-  if (N > RK_BUCKET_MIN) {
-    char* p = (char*)ws + n64 * (sizeof(uint64_t) + sizeof(int32_t)) + 256;
-    auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-    uint64_t* bkeys = (uint64_t*)take(n64 * 8);
-    int32_t* bidx = (int32_t*)take(n64 * 4);
-    int32_t* slot = (int32_t*)take(n64 * 4);
-    uint8_t* bid = (uint8_t*)take(n64);
-    uint64_t* samp = (uint64_t*)take(RK_NSAMPLE * 8);
-    int32_t* perm_s = (int32_t*)take(RK_NSAMPLE * 4);
-    uint64_t* spl = (uint64_t*)take(RK_NBUCKET * 8);
-    int32_t* cnt = (int32_t*)take(RK_NBUCKET * 4);
-    int32_t* off = (int32_t*)take((RK_NBUCKET + 1) * 4);
-    rank_sample_kernel<<<RK_NSAMPLE / 256, 256, 0, s>>>(keys, N, samp);
-    LTR_LAUNCH_CHECK();
-    rank_count_kernel<true><<<dim3(RK_NSAMPLE / RK_ITILE, 1), RK_THREADS, 0, s>>>(samp, RK_NSAMPLE, RK_NSAMPLE, rank, perm_s);
-    LTR_LAUNCH_CHECK();
-    rank_splitters_kernel<<<1, RK_NBUCKET, 0, s>>>(samp, perm_s, spl, cnt);
-    LTR_LAUNCH_CHECK();
-    rank_assign_kernel<<<(N + RK_ASSIGN_THREADS * RK_ASSIGN_KEYS - 1) / (RK_ASSIGN_THREADS * RK_ASSIGN_KEYS), RK_ASSIGN_THREADS, 0, s>>>(
-        keys, N, spl, cnt, bid, slot);
-    LTR_LAUNCH_CHECK();
-    rank_bucket_scan_kernel<<<1, RK_NBUCKET, 0, s>>>(cnt, off);
-    LTR_LAUNCH_CHECK();
-    rank_bucket_scatter_kernel<<<(N + 255) / 256, 256, 0, s>>>(keys, N, bid, slot, off, bkeys, bidx);
-    LTR_LAUNCH_CHECK();
-    rank_in_bucket_kernel<<<RK_NBUCKET, 256, 0, s>>>(bkeys, bidx, off, perm_out);
-    LTR_LAUNCH_CHECK();
-    return LTR_OK;
-  }
-  const int itiles = (N + RK_ITILE - 1) / RK_ITILE;
-  // spread the j range so that the grid holds >= ~512 workgroups; slices are multiples of the chunk
-  int js = 1;
-  while (itiles * js < 512 && (int64_t)js * RK_CHUNK < N) js *= 2;
-  int j_per_block = (int)((((int64_t)N + js - 1) / js + RK_CHUNK - 1) / RK_CHUNK * RK_CHUNK);
-  js = (N + j_per_block - 1) / j_per_block;
-  if (js == 1) {
-    rank_count_kernel<true><<<dim3(itiles, 1), RK_THREADS, 0, s>>>(keys, N, j_per_block, rank, perm_out);
-    LTR_LAUNCH_CHECK();
-  } else {
-    rank_count_kernel<false><<<dim3(itiles, js), RK_THREADS, 0, s>>>(keys, N, j_per_block, rank, perm_out);
-    LTR_LAUNCH_CHECK();
-    rank_scatter_kernel<<<(N + 255) / 256, 256, 0, s>>>(rank, N, perm_out);
-    LTR_LAUNCH_CHECK();
-  }
+  char* p = (char*)ws + n64 * (sizeof(uint64_t) + sizeof(int32_t)) + 256;
+  auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+  uint64_t* bkeys = (uint64_t*)take(n64 * 8);
+  int32_t* bidx = (int32_t*)take(n64 * 4);
+  int32_t* slot = (int32_t*)take(n64 * 4);
+  uint8_t* bid = (uint8_t*)take(n64);
+  uint64_t* samp = (uint64_t*)take(RK_NSAMPLE * 8);
+  int32_t* perm_s = (int32_t*)take(RK_NSAMPLE * 4);
+  uint64_t* spl = (uint64_t*)take(RK_NBUCKET * 8);
+  int32_t* cnt = (int32_t*)take(RK_NBUCKET * 4);
+  int32_t* off = (int32_t*)take((RK_NBUCKET + 1) * 4);
+  rank_sample_kernel<<<RK_NSAMPLE / 256, 256, 0, s>>>(keys, N, samp);
+  LTR_LAUNCH_CHECK();
+  rank_count_kernel<<<RK_NSAMPLE / RK_ITILE, RK_THREADS, 0, s>>>(samp, RK_NSAMPLE, perm_s);
+  LTR_LAUNCH_CHECK();
+  rank_splitters_kernel<<<1, RK_NBUCKET, 0, s>>>(samp, perm_s, spl, cnt);
+  LTR_LAUNCH_CHECK();
+  rank_assign_kernel<<<(N + RK_ASSIGN_THREADS * RK_ASSIGN_KEYS - 1) / (RK_ASSIGN_THREADS * RK_ASSIGN_KEYS), RK_ASSIGN_THREADS, 0, s>>>(
+      keys, N, spl, cnt, bid, slot);
+  LTR_LAUNCH_CHECK();
+  rank_bucket_scan_kernel<<<1, RK_NBUCKET, 0, s>>>(cnt, off);
+  LTR_LAUNCH_CHECK();
+  rank_bucket_scatter_kernel<<<(N + 255) / 256, 256, 0, s>>>(keys, N, bid, slot, off, bkeys, bidx);
+  LTR_LAUNCH_CHECK();
+  rank_in_bucket_kernel<<<RK_NBUCKET, 256, 0, s>>>(bkeys, bidx, off, perm_out);
+  LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
 
-int launch_age_update(const uint8_t* ran, int32_t* pri, int32_t* idle, int32_t* runs, int N, hipStream_t s) {
+}  // namespace
+
+int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                     const int32_t* members, int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
   if (N == 0) return LTR_OK;
-  age_update_kernel<<<(N + 255) / 256, 256, 0, s>>>(ran, pri, idle, runs, N);
+  int rc = check_rank_args(pri, idle, runs, starv, flags);
+  if (rc) return rc;
+  if (N > RK_BUCKET_MIN)
+    return launch_rank_bucketed(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, ws,
+                                ws_bytes, s);
+  rank_fused_kernel<<<(N + 63) / 64, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags,
+                                                  perm_out);
+  LTR_LAUNCH_CHECK();
+  if (starv != -1) {
+    rank_apply_kernel<<<(N + 255) / 256, 256, 0, s>>>(pri, idle, runs, members, N, starv, period);
+    LTR_LAUNCH_CHECK();
+  }
+  return LTR_OK;
+}
+
+int launch_queue_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                      const int32_t* members, int N, int starv, int period, uint32_t flags, const int32_t* new_tokens,
+                      const int32_t* new_seqs, const uint8_t* chunkable, int64_t token_budget, int64_t max_seqs,
+                      int32_t* perm_out, int32_t* n_sel, uint8_t* ran, int32_t* granted, void* ws, size_t ws_bytes,
+                      hipStream_t s) {
+  int rc = check_rank_args(pri, idle, runs, starv, flags);
+  if (rc) return rc;
+  int apply_promote = 1;
+  if (N > RK_BUCKET_MIN) {
+    rc = launch_rank_bucketed(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, ws,
+                              ws_bytes, s);
+    if (rc) return rc;
+    apply_promote = 0;                                  // rank_prepare_kernel already wrote the promote/demote
+  } else if (N > 0) {
+    rank_fused_kernel<<<(N + 63) / 64, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period,
+                                                    flags, perm_out);
+    LTR_LAUNCH_CHECK();
+  }
+  queue_tail_kernel<<<1, BP_THREADS, 0, s>>>(perm_out, members, new_tokens, new_seqs, chunkable, N,
+                                             (long long)token_budget, (long long)max_seqs, starv, period,
+                                             apply_promote, (pri && idle && runs) ? pri : nullptr, idle, runs, n_sel, ran,
+                                             granted);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
 
-int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs, int N,
-                         int64_t token_budget, int64_t max_seqs, int32_t* n_sel, uint8_t* ran, int32_t* granted,
-                         hipStream_t s) {
-  budget_prefix_kernel<<<1, BP_THREADS, 0, s>>>(perm, new_tokens, new_seqs, N, (long long)token_budget,
+int launch_age_update(const uint8_t* ran, const int32_t* ran_slots, int n_ran, int32_t* pri, int32_t* idle,
+                      int32_t* runs, const int32_t* members, int N, hipStream_t s) {
+  if (N == 0) return LTR_OK;
+  age_update_kernel<<<(N + 255) / 256, 256, 0, s>>>(ran, ran_slots, n_ran, pri, idle, runs, members, N);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int launch_budget_prefix(const int32_t* perm, const int32_t* new_tokens, const int32_t* new_seqs,
+                         const uint8_t* chunkable, int N, int64_t token_budget, int64_t max_seqs, int32_t* n_sel,
+                         uint8_t* ran, int32_t* granted, hipStream_t s) {
+  budget_prefix_kernel<<<1, BP_THREADS, 0, s>>>(perm, new_tokens, new_seqs, chunkable, N, (long long)token_budget,
                                                 (long long)max_seqs, n_sel, ran, granted);
   LTR_LAUNCH_CHECK();
   if (N > 0 && (ran != nullptr || granted != nullptr)) {

@@ -64,7 +64,7 @@ template <typename WT, bool PROJ>
 __global__ void __launch_bounds__(256) embed_gather_kernel(
     const int64_t* __restrict__ ids, const int32_t* __restrict__ cu, int n_req, int T, int tok_off,
     const WT* __restrict__ tok_table, int De, int vocab, const WT* __restrict__ pos_table, int H,
-    int pos_rows, float* __restrict__ hidden, void* tok_hi, void* tok_lo) {
+    int pos_rows, float* __restrict__ hidden, void* tok_hi, void* tok_lo, int32_t* __restrict__ err_flag) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);   // row inside this chunk
   if (t >= T) return;
@@ -73,7 +73,12 @@ __global__ void __launch_bounds__(256) embed_gather_kernel(
   int pos = tg - cu[req] + 2;                                        // opt.py:43-53 offset
   pos = min(pos, pos_rows - 1);
   long long id = ids[tg];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);                  // F.embedding would raise; clamp instead of faulting
+  if (id < 0 || id >= vocab) {
+    // F.embedding raises here (vocab_parallel_embedding.py:95-106).  Flag it for ltr_status and read a valid
+    // row instead of faulting; the scores of this call are invalid.
+    if (lane == 0 && err_flag != nullptr) atomicOr(err_flag, 1);
+    id = id < 0 ? 0 : vocab - 1;
+  }
   const WT* trow = tok_table + (size_t)id * De;
   const WT* prow = pos_table + (size_t)pos * H;
   float* hrow = hidden + (size_t)t * H;
@@ -208,17 +213,17 @@ __global__ void __launch_bounds__(256) to_operand_kernel(const float* __restrict
 
 int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N, int T, int tok_off,
                         const void* tok_table, int De, int vocab, const void* pos_table, int H, int pos_rows,
-                        float* hidden_out, AOp tok_out, hipStream_t s) {
+                        float* hidden_out, AOp tok_out, int32_t* err_flag, hipStream_t s) {
   if (T == 0) return LTR_OK;
   if ((H % 8) || (De % 8)) { set_error("embed_gather: H and De must be multiples of 8"); return LTR_E_INVAL; }
   dim3 grid((T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const bool proj = De != H;
   if (wdtype == LTR_W_F16) {
-    if (proj) embed_gather_kernel<__half, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo);
-    else embed_gather_kernel<__half, false><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, nullptr, nullptr);
+    if (proj) embed_gather_kernel<__half, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo, err_flag);
+    else embed_gather_kernel<__half, false><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, nullptr, nullptr, err_flag);
   } else {
-    if (proj) embed_gather_kernel<float, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const float*)tok_table, De, vocab, (const float*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo);
-    else embed_gather_kernel<float, false><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const float*)tok_table, De, vocab, (const float*)pos_table, H, pos_rows, hidden_out, nullptr, nullptr);
+    if (proj) embed_gather_kernel<float, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const float*)tok_table, De, vocab, (const float*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo, err_flag);
+    else embed_gather_kernel<float, false><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const float*)tok_table, De, vocab, (const float*)pos_table, H, pos_rows, hidden_out, nullptr, nullptr, err_flag);
   }
   LTR_LAUNCH_CHECK();
   return LTR_OK;

@@ -78,24 +78,33 @@ __global__ void __launch_bounds__(LM_THREADS) listmle_kernel(const float* __rest
   for (int i = tid; i < S; i += LM_THREADS) cw[i] = ce[i];          // keep exp() before it is overwritten by the scan
   __syncthreads();
   block_scan(ce, S, true, part);                                     // ce[i] = sum_{j >= i} exp
-  float ls = 0.f;
+  float ls = 0.f, mp = 0.f;
+  int amax = S;
   for (int i = tid; i < S; i += LM_THREADS) {
     const bool masked = sp[i] == -INFINITY;
     const float e = cw[i], c = ce[i];
-    if (!masked) ls += logf(c + eps) - (sp[i] - mx);
+    if (!masked) {
+      ls += logf(c + eps) - (sp[i] - mx);
+      mp += eps / (c + eps);                                         // d obs_i / d max (the path through max_pred_values)
+      if (sp[i] == mx) amax = min(amax, i);
+    }
     ts[i] = e;                                                       // ts is dead: exp() per sorted position
     cw[i] = masked ? 0.f : 1.f / (c + eps);
   }
   ls = block_reduce(ls, red, false);
   if (tid == 0) row_loss[b] = ls;
   if (grad == nullptr) return;
+  // autograd routes d loss / d max to the arg-max item (first one in sorted order): negligible while every
+  // cumsum >> eps, ~1 per trailing item once exp(p_i - max) < eps (score spread above ~23)
+  mp = block_reduce(mp, red, false);
+  amax = -(int)block_reduce((float)-amax, red, true);                // min over the block (S <= 4096: exact in f32)
   __syncthreads();
   block_scan(cw, S, false, part);                                    // cw[i] = sum_{k <= i} 1 / (c_k + eps)
   const float invB = 1.f / (float)B;
   for (int j = tid; j < S; j += LM_THREADS) {
     const int r = rk[j];
     const bool masked = sp[r] == -INFINITY;
-    grad[(size_t)b * S + shuffle[j]] = masked ? 0.f : (ts[r] * cw[r] - 1.f) * invB;
+    grad[(size_t)b * S + shuffle[j]] = masked ? 0.f : (ts[r] * cw[r] - 1.f + (r == amax ? mp : 0.f)) * invB;
   }
 }
 

@@ -51,55 +51,96 @@ def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None) -> tor
     mx = max(max(counts), 1)
     buf = torch.zeros(mx, dtype=torch.float32, device=local.device)
     buf[:local.numel()] = local
-    out = torch.empty(world * mx, dtype=torch.float32, device=local.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # gloo has no CUDA all-gather: stage through the host.  Only the one-device dry run of the N-rank path
+        # (tests, LTR_BENCH_BACKEND=gloo) comes here; production is RCCL ("nccl") on device buffers.
+        out_h = torch.empty(world * mx, dtype=torch.float32)
+        dist.all_gather_into_tensor(out_h, buf.cpu(), group=group)
+        out = out_h.to(local.device)
+    else:
+        out = torch.empty(world * mx, dtype=torch.float32, device=local.device)
+        dist.all_gather_into_tensor(out, buf, group=group)
     out = out.view(world, mx)
     return torch.cat([out[r, :counts[r]] for r in range(world)])
 
 
 class ShardedScorer:
-    """SPMD wrapper: every rank calls :meth:`score` with the SAME (ids, cu_seqlens) and
+    """SPMD wrapper: every rank calls :meth:`score` / :meth:`score_device` with the SAME batch and
     gets the full score vector back.
 
-    score_fn(ids_shard, cu_shard) -> f32 tensor [n_shard] on this rank's device (the
-    HIP predictor in production: ``lambda i, c: scorer.score_device(...)``).
+    scorer: the HIP predictor (:class:`~vllm_ltr_amd.scorer.HipOPTScorer`; anything with
+    ``score_device(ids_dev, cu_dev, cu_host)``), or a plain ``score_fn(ids_shard, cu_shard) -> f32
+    tensor [n_shard]`` over host arrays (the CPU tests put the oracle there).
     min_requests_to_shard: below it the launch + collective latency outweighs the split
     (north_star: 'only when the queue exceeds a single GPU's batch'); rank 0 scores alone
     and broadcasts.
     """
 
-    def __init__(self, score_fn: Callable[[np.ndarray, np.ndarray], torch.Tensor], device,
-                 group=None, min_requests_to_shard: int = 1024):
+    def __init__(self, scorer, device, group=None, min_requests_to_shard: int = 1024):
         import torch.distributed as dist
         self.dist = dist
-        self.score_fn = score_fn
+        self.scorer = scorer if hasattr(scorer, "score_device") else None
+        self.score_fn: Optional[Callable[[np.ndarray, np.ndarray], torch.Tensor]] = None if self.scorer else scorer
         self.device = torch.device(device)
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.min_requests_to_shard = int(min_requests_to_shard)
 
-    def score(self, ids: np.ndarray, cu_seqlens: np.ndarray) -> torch.Tensor:
-        cu = np.asarray(cu_seqlens, dtype=np.int64)
-        n = cu.shape[0] - 1
-        if n <= 0:
-            return torch.zeros(0, dtype=torch.float32, device=self.device)
+    # ---- the collective part (same on both entry points)
+    def _exchange(self, n: int, sharded: bool, bounds, local_fn, whole_fn) -> torch.Tensor:
         if self.world == 1:
-            return self.score_fn(ids, cu.astype(np.int32))
-        if n < self.min_requests_to_shard:            # same decision on every rank (same n)
+            return whole_fn()
+        if not sharded:                                  # same decision on every rank (same n)
             if self.rank == 0:
-                s = self.score_fn(ids, cu.astype(np.int32)).to(self.device, torch.float32)
+                s = whole_fn().to(self.device, torch.float32)
             else:
                 s = torch.empty(n, dtype=torch.float32, device=self.device)
             self.dist.broadcast(s, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
                                 group=self.group)
             return s
-        bounds = shard_bounds(cu, self.world)
         r0, r1 = bounds[self.rank]
         if r1 > r0:
-            ids_s = np.asarray(ids)[cu[r0]:cu[r1]]
-            cu_s = (cu[r0:r1 + 1] - cu[r0]).astype(np.int32)
-            local = self.score_fn(ids_s, cu_s).to(self.device, torch.float32)
+            local = local_fn(r0, r1).to(self.device, torch.float32)
         else:
             local = torch.zeros(0, dtype=torch.float32, device=self.device)
         return gather_scores(local, [b - a for a, b in bounds], self.group)
+
+    def _local_host(self, ids, cu):
+        if self.scorer is not None:
+            ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+            cu32 = np.ascontiguousarray(cu, dtype=np.int32)
+            return self.scorer.score_device(ids_d, torch.from_numpy(cu32).to(self.device), cu32)
+        return self.score_fn(ids, cu.astype(np.int32))
+
+    def score(self, ids: np.ndarray, cu_seqlens: np.ndarray) -> torch.Tensor:
+        """Host arrays in (identical on every rank); each rank uploads and scores only its shard."""
+        cu = np.asarray(cu_seqlens, dtype=np.int64)
+        n = cu.shape[0] - 1
+        if n <= 0:
+            return torch.zeros(0, dtype=torch.float32, device=self.device)
+        sharded = n >= self.min_requests_to_shard
+        bounds = shard_bounds(cu, self.world) if sharded and self.world > 1 else None
+        ids = np.asarray(ids)
+        return self._exchange(n, sharded, bounds,
+                              lambda r0, r1: self._local_host(ids[cu[r0]:cu[r1]], cu[r0:r1 + 1] - cu[r0]),
+                              lambda: self._local_host(ids, cu))
+
+    def score_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray) -> torch.Tensor:
+        """The whole batch is resident on every rank's device (ids int64 [T], cu int32 [N+1] + host mirror);
+        each rank scores its slice of it in place - no copies, one all-gather of the scores."""
+        assert self.scorer is not None, "score_device needs a device scorer"
+        cu = np.asarray(cu_host, dtype=np.int64)
+        n = cu.shape[0] - 1
+        if n <= 0:
+            return torch.zeros(0, dtype=torch.float32, device=self.device)
+        sharded = n >= self.min_requests_to_shard
+        bounds = shard_bounds(cu, self.world) if sharded and self.world > 1 else None
+
+        def local(r0, r1):
+            t0 = int(cu[r0])
+            cu_s = (cu[r0:r1 + 1] - t0).astype(np.int32)
+            cu_d = cu_dev[r0:r1 + 1] - t0 if t0 else cu_dev[r0:r1 + 1]
+            return self.scorer.score_device(ids_dev[t0:int(cu[r1])], cu_d.contiguous(), cu_s)
+        return self._exchange(n, sharded, bounds, local,
+                              lambda: self.scorer.score_device(ids_dev, cu_dev, np.ascontiguousarray(cu_host, np.int32)))

@@ -15,10 +15,19 @@ What the reference wires (all paths relative to the reference checkout):
   (vllm/entrypoints/aux_llm.py:125-126 -> vllm/engine/aux_llm_engine.py:332-412): sets
   ``aux_model_score`` on every group via ``set_aux_model_score`` and returns the scores;
 * ``ordered_requests(scheduler)`` - the body of ``_get_opt_ordered_requests`` (and the
-  ``tpt/rtpt/ropt`` variants) with the promote/demote + sort done by ``ltr_rank_step``;
+  ``tpt/rtpt/ropt/xpt`` variants) with the promote/demote + sort done by ``ltr_rank_step``;
 * ``age(all_pri, running_this_step)`` - the aging loop done by ``ltr_age_update``;
 * ``install(scheduler)`` - assigns ``scheduler.aux_model`` and rebinds
-  ``scheduler._get_ordered_requests`` exactly where ``scheduler.py:325-329`` binds them.
+  ``scheduler._schedule / _get_ordered_requests`` exactly where ``scheduler.py:319-329`` binds them.
+
+**Device-resident queue** (SURVEY.md 7).  The ranking state of a request - score, ``pri``, ``idle``,
+``runs`` - lives in a slot of a :class:`~vllm_ltr_amd.rank.DeviceQueue` from the first time the ranker
+sees the request until it leaves the scheduler's deques.  Per scheduler step the host only (1) lists the
+deques, (2) reads the slot number off each request (one C-level pass), (3) uploads that ``members`` array
+(4 B per request) and (4) builds the output list from the returned permutation; ``age`` uploads the slots
+of the <= ``max_num_seqs`` requests that ran.  Nothing in the reference outside scheduler.py:984-993 and
+:1358-1365 reads ``pri/idle/runs``, so the host attributes are refreshed only on request
+(:meth:`sync_host`, or ``mirror_host=True`` to write them back every step like the reference does).
 
 Requests are duck-typed on the fields the reference touches: ``request_id``,
 ``aux_model_score`` / ``need_aux_model_score()`` / ``set_aux_model_score()``
@@ -27,6 +36,8 @@ prompt (``prompt`` text or ``prompt_token_ids``).
 """
 from __future__ import annotations
 
+import itertools
+import operator
 import os
 import time
 from typing import Callable, Iterable, List, Optional, Sequence
@@ -38,9 +49,11 @@ from . import _lib
 from .config_predictor import PrefillPredictorConfig
 from .host_pipeline import InputStager, cached_token_ids
 from .opt_spec import OPTSpec, load_hf_checkpoint
-from .rank import RankWorkspace, age_update, budget_prefix, rank_step, reserve_select
+from .rank import DeviceQueue, RankWorkspace, budget_prefix, rank_step, reserve_select
 from .schedule_type import ScheduleType, parse_schedule_type
 from .scorer import HipOPTScorer
+
+_ranker_ids = itertools.count()
 
 
 def _string_rank(request_ids: Sequence[str]) -> np.ndarray:
@@ -52,13 +65,38 @@ def _string_rank(request_ids: Sequence[str]) -> np.ndarray:
     return rank
 
 
+class _PinnedI32:
+    """Growable pinned int32 staging buffer + device twin (members / ran slots / permutation)."""
+
+    def __init__(self, device, cap: int = 1 << 13):
+        self.device = device
+        self._grow(cap)
+
+    def _grow(self, cap: int):
+        self.cap = cap
+        self.host = torch.empty(cap, dtype=torch.int32).pin_memory()
+        self.np = self.host.numpy()
+        self.dev = torch.empty(cap, dtype=torch.int32, device=self.device)
+
+    def ensure(self, n: int):
+        if n > self.cap:
+            self._grow(max(n, 2 * self.cap))
+
+    def upload(self, n: int) -> torch.Tensor:
+        d = self.dev[:n]
+        d.copy_(self.host[:n], non_blocking=True)
+        return d
+
+
 class MI355XRanker:
     def __init__(self, scorer: HipOPTScorer, schedule_type: str = "opt", max_length: int = 2048,
                  tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank",
-                 xpt_distribution=None):
+                 xpt_distribution=None, group=None, min_requests_to_shard: int = 1024,
+                 mirror_host: bool = False):
         """
         scorer      the HBM-resident predictor
-        schedule_type  the reference's schedule string (``opt-...-starv<S>-period<P>``)
+        schedule_type  the reference's schedule string (``opt-...-starv<S>-period<P>``; an ``xpt{path}...``
+                    string names its score -> expected-length table like scheduler.py:312)
         max_length  prompt truncation, ``PrefillModelConfig.max_length`` = the AUX engine's
                     ``max_model_len`` (aux_llm_engine.py:365-369, llm_engine.py:236)
         tokenize    text -> predictor token ids.  The reference re-tokenises the prompt
@@ -66,6 +104,12 @@ class MI355XRanker:
                     pass that tokenizer's ``encode`` here.  None: use the request's
                     ``prompt_token_ids`` (valid when backbone and predictor share a
                     tokenizer, and for synthetic workloads).
+        group       a ``torch.distributed`` process group: ``obtain_aux_scores`` then shards the batch over the
+                    ranks of the group (every rank must make the same call, SPMD) with one all-gather of the
+                    scores (RCCL over xGMI); the reference instead runs the predictor tensor-parallel over the
+                    backbone's TP group (llm_engine.py:237).  None: this GPU scores alone.
+        mirror_host write ``pri/idle/runs`` back to the request objects every step (what the reference's loops
+                    do; costs a D2H copy + a Python loop per step).  Default: device-resident only.
         """
         self.scorer = scorer
         self.device = scorer.device
@@ -73,27 +117,99 @@ class MI355XRanker:
         self.max_length = int(max_length)
         self.tokenize = tokenize
         self.mtype = mtype
-        # xpt policy: (key, value) score -> expected-length table, scheduler.py:312 (torch.load(...))
+        # xpt policy: (key, value) score -> expected-length table, scheduler.py:312 (torch.load of the {path})
         self.xpt_distribution = xpt_distribution
+        if self.xpt_distribution is None and self.st.policy == "xpt" and self.st.table_path:
+            self.xpt_distribution = torch.load(self.st.table_path)
         if mtype == "rank" and scorer.spec.num_labels != 1:
             raise ValueError("mtype 'rank' needs num_labels == 1 (prefill_predictor.py:35-36)")
+        self.mirror_host = bool(mirror_host)
         self._ws = RankWorkspace(self.device)
         self._stager = InputStager(self.device)
+        self._sharded = None
+        if group is not None:
+            from .distributed import ShardedScorer
+            self._sharded = ShardedScorer(self.scorer, self.device, group=group,
+                                          min_requests_to_shard=min_requests_to_shard)
+        starv, period = (self.st.starv, self.st.period) if self.st.policy == "opt" else (-1, 0)
+        self.queue = DeviceQueue(self.device, starv=starv, period=period, capacity=1 << 13)
+        # the slot number lives on the request object under a per-ranker attribute name (two rankers - e.g. in a
+        # test - must not read each other's slots); attrgetter keeps the per-step pass over the queue in C
+        self._slot_attr = f"_ltr_slot{next(_ranker_ids)}"
+        self._get_slot = operator.attrgetter(self._slot_attr)
+        self._members = _PinnedI32(self.device)
+        self._perm = _PinnedI32(self.device)
+        self._ran = _PinnedI32(self.device, 1 << 10)
+        self._n_members = 0
+        self._members_dev: Optional[torch.Tensor] = None
+        self._live_slots = 0
         self.stats = dict(aux_calls=0, requests_scored=0, rank_calls=0, score_seconds=0.0, rank_seconds=0.0)
 
     # ---- construction from the reference's config objects ------------------------------
     @classmethod
     def from_predictor_config(cls, cfg, schedule_type: str, device: str = "cuda:0", tokenize=None,
-                              weight_dtype: str = "f16") -> "MI355XRanker":
+                              weight_dtype: str = "f16", **kw) -> "MI355XRanker":
         """``cfg``: a :class:`PrefillPredictorConfig` or a path to its JSON
         (``--prefill-predictor-model-config``, arg_utils.py:346-359).  Loads the HF
-        checkpoint at ``cfg.model.path`` like llm_engine.py:228-240 does for the AUXLLM."""
+        checkpoint at ``cfg.model.path`` like llm_engine.py:228-240 does for the AUXLLM.
+        Extra keywords (``xpt_distribution``, ``group``, ...) go to the constructor."""
         if isinstance(cfg, (str, os.PathLike)):
             cfg = PrefillPredictorConfig.from_json(cfg)
         spec, ckpt = load_hf_checkpoint(cfg.model.path)
         scorer = HipOPTScorer(spec, ckpt, device=device, weight_dtype=weight_dtype)
         return cls(scorer, schedule_type, max_length=cfg.model.max_length, tokenize=tokenize,
-                   mtype=cfg.model.mtype)
+                   mtype=cfg.model.mtype, **kw)
+
+    # ---- slots ------------------------------------------------------------------------------
+    def _assign_slots(self, reqs: Sequence, being_scored: bool = False) -> None:
+        """Give every request of ``reqs`` that has none a slot.  A request that already carries a score (set by
+        someone else, or before this ranker was installed) gets it - and its counters - uploaded."""
+        attr = self._slot_attr
+        fresh = [r for r in reqs if not hasattr(r, attr)]
+        if not fresh:
+            return
+        if not being_scored:
+            for r in fresh:
+                if getattr(r, "aux_model_score", None) is None:
+                    # the reference fails here too: sorted() would negate None (scheduler.py:996)
+                    raise TypeError(f"request {r.request_id} reaches the ordering without an aux_model_score")
+        slots = self.queue.alloc_slots(len(fresh))
+        have = []
+        for r, s in zip(fresh, slots):
+            setattr(r, attr, int(s))
+            if getattr(r, "aux_model_score", None) is not None:
+                have.append((int(s), float(r.aux_model_score), int(getattr(r, "pri", 0)), int(getattr(r, "idle", 0)),
+                             int(getattr(r, "runs", 0))))
+        self._live_slots += len(fresh)
+        if have:     # adopted mid-flight: carry score and counters over
+            a = np.asarray(have, np.float64)
+            idx = torch.from_numpy(a[:, 0].astype(np.int64)).to(self.device)
+            self.queue._score.index_copy_(0, idx, torch.from_numpy(a[:, 1].astype(np.float32)).to(self.device))
+            for col, t in ((2, self.queue._pri), (3, self.queue._idle), (4, self.queue._runs)):
+                t.index_copy_(0, idx, torch.from_numpy(a[:, col].astype(np.int32)).to(self.device))
+
+    def _collect_members(self, reqs: Sequence) -> int:
+        """Slots of ``reqs`` into the pinned members buffer (one C-level pass); returns n."""
+        n = len(reqs)
+        self._members.ensure(n)
+        try:
+            self._members.np[:n] = np.fromiter(map(self._get_slot, reqs), np.int32, n)
+        except AttributeError:           # requests the ranker has not seen yet (adopted mid-flight, direct order() calls)
+            self._assign_slots(reqs)
+            self._members.np[:n] = np.fromiter(map(self._get_slot, reqs), np.int32, n)
+        return n
+
+    def _gc_slots(self, n_members: int) -> None:
+        """Requests that left the deques (finished / aborted) never come back: reclaim their slots once the
+        live count has drifted well past the queue size."""
+        if self._live_slots <= 2 * n_members + 1024:
+            return
+        used = np.zeros(self.queue.n, bool)
+        used[self._members.np[:n_members]] = True
+        used[np.asarray(self.queue._free, np.int64)] = True
+        dead = np.nonzero(~used)[0]
+        self.queue.free_slots(dead.tolist())
+        self._live_slots -= len(dead)
 
     # ---- AUXLLM.obtain_aux_scores -------------------------------------------------------
     def add_request(self, sg) -> None:
@@ -110,7 +226,17 @@ class MI355XRanker:
             assert sg.need_aux_model_score()               # aux_llm_engine.py:409
         arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in seq_groups]
         ids_dev, cu_dev, cu_host = self._stager.stage(arrays)          # pinned pack + async H2D
-        scores = self._stager.fetch_scores(self.scorer.score_device(ids_dev, cu_dev, cu_host))
+        if self._sharded is not None:
+            scores_dev = self._sharded.score_device(ids_dev, cu_dev, cu_host)
+        else:
+            scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host)
+        # the scores stay on the device in the requests' slots; the host copy is only for the
+        # reference-visible ``aux_model_score`` attribute
+        self._assign_slots(seq_groups, being_scored=True)
+        slots = torch.from_numpy(np.fromiter(map(self._get_slot, seq_groups), np.int64, len(seq_groups))).to(self.device)
+        self.queue.set_scores(slots, scores_dev)
+        scores = self._stager.fetch_scores(scores_dev)
+        self.scorer.check_status()                         # out-of-vocabulary ids raise, like F.embedding
         out = scores.tolist()                              # opt.py:408 .tolist()
         for sg, s in zip(seq_groups, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
@@ -122,39 +248,43 @@ class MI355XRanker:
     # ---- Scheduler._get_*_ordered_requests ------------------------------------------------
     def order(self, reqs: Sequence, policy: Optional[str] = None) -> list:
         """Promote/demote (when starvation control is on) and order ``reqs`` (already the
-        concatenation waiting+running+swapped, all scored).  Mutates ``pri/idle/runs`` on the
-        request objects like scheduler.py:986-993 and returns the new list."""
+        concatenation waiting+running+swapped, all scored); scheduler.py:984-998.  The counters are
+        updated in the device-resident slots (see :meth:`sync_host`)."""
         n = len(reqs)
         if n == 0:
+            self._n_members = 0
             return []
         t0 = time.perf_counter()
         policy = policy or self.st.policy
-        starv, period = (self.st.starv, self.st.period) if policy == "opt" else (-1, 0)
-        if policy == "xpt":                                                      # scheduler.py:910-933
+        n = self._collect_members(reqs)
+        members = self._members.upload(n)
+        self._members_dev, self._n_members = members, n
+        q = self.queue
+        self._perm.ensure(n)
+        perm_dev = self._perm.dev[:n]
+        if policy == "opt":
+            rank_step(q._score, q._pri, q._idle, q._runs, q.starv, q.period, self._ws, out=perm_dev, members=members)
+        elif policy == "xpt":                                                    # scheduler.py:910-933
             keys = np.fromiter((self._xpt_key(r) for r in reqs), np.float32, n)
-            score = torch.from_numpy(keys).to(self.device)
+            rank_step(torch.from_numpy(keys).to(self.device), None, None, None, -1, 0, self._ws, ascending=True,
+                      out=perm_dev)
         else:
-            score = torch.from_numpy(np.fromiter((r.aux_model_score for r in reqs), np.float32, n)).to(self.device)
-        pri = idle = runs = None
-        if starv != -1:
-            st = np.empty((3, n), np.int32)
-            for i, r in enumerate(reqs):
-                st[0, i] = r.pri; st[1, i] = r.idle; st[2, i] = r.runs
-            dev = torch.from_numpy(st).to(self.device)
-            pri, idle, runs = dev[0], dev[1], dev[2]
-        tiebreak = None
-        ascending = policy in ("ropt", "rtpt", "xpt")                            # scheduler.py:933,961,1015
-        if policy in ("tpt", "rtpt"):                                            # scheduler.py:948,961
-            tiebreak = torch.from_numpy(_string_rank([r.request_id for r in reqs])).to(self.device)
-        perm = rank_step(score, pri, idle, runs, starv, period, self._ws, tiebreak=tiebreak, ascending=ascending)
-        perm_h = perm.cpu().numpy()
-        if starv != -1:
-            st = dev.cpu().numpy()
-            for i, r in enumerate(reqs):
-                r.pri = int(st[0, i]); r.idle = int(st[1, i]); r.runs = int(st[2, i])
+            tiebreak = None
+            if policy in ("tpt", "rtpt"):                                        # scheduler.py:948,961
+                tiebreak = torch.from_numpy(_string_rank([r.request_id for r in reqs])).to(self.device)
+            rank_step(q._score, None, None, None, -1, 0, self._ws, tiebreak=tiebreak,
+                      ascending=policy in ("ropt", "rtpt"), out=perm_dev, members=members)   # scheduler.py:961,1015
+        host = self._perm.host[:n]
+        host.copy_(perm_dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        perm = self._perm.np[:n].tolist()
+        out = list(operator.itemgetter(*perm)(reqs)) if n > 1 else [reqs[perm[0]]]
+        if self.mirror_host and policy == "opt" and q.starv != -1:
+            self.sync_host(reqs)
+        self._gc_slots(n)
         self.stats["rank_calls"] += 1
         self.stats["rank_seconds"] += time.perf_counter() - t0
-        return [reqs[i] for i in perm_h]
+        return out
 
     def _xpt_key(self, req) -> float:
         """expected_length(score) - output_len, the SRTF key of scheduler.py:920-933.  The table
@@ -175,37 +305,65 @@ class MI355XRanker:
 
     def ordered_requests(self, scheduler, policy: Optional[str] = None) -> list:
         """scheduler.py:969-1000 (and :936-948, :951-961, :1005-1015 for tpt/rtpt/ropt)."""
-        need = [r for r in scheduler.waiting if r.need_aux_model_score()]
+        waiting = scheduler.waiting
+        # unscored requests = the arrivals since the last call: a suffix of the waiting deque
+        # (add_seq_group appends, scheduler.py:376; preempted requests are pushed to the FRONT and are scored
+        # already).  Walking back from the tail until the first scored request replaces the reference's scan
+        # of the whole deque (:971-975) without changing the set.
+        # (A scheduler that breaks this invariant fails loudly in order(): a request without a score and without
+        # a slot raises, as the reference's sorted() would on -None.)
+        need = []
+        for r in reversed(waiting):
+            if not r.need_aux_model_score():
+                break
+            need.append(r)
+        need.reverse()
         if need:
             timed = int(os.environ.get("OPT_TIME", 0))                           # scheduler.py:977-982
             t0 = time.time()
             scheduler.aux_model.obtain_aux_scores(need)
             if timed:
                 print("OPT-TIME: ", time.time() - t0)
-        reqs = list(scheduler.waiting) + list(scheduler.running) + list(scheduler.swapped)
+        reqs = list(waiting) + list(scheduler.running) + list(scheduler.swapped)
         return self.order(reqs, policy)
 
     # ---- aging loop of _general_schedule ----------------------------------------------------
     def age(self, all_pri: Sequence, running_this_step: Iterable) -> None:
-        """scheduler.py:1358-1365 on the request objects, computed by ltr_age_update."""
+        """scheduler.py:1358-1365, computed by ltr_age_update on the device-resident slots: only the slots of
+        ``running_this_step`` (<= max_num_seqs) are uploaded; the members of the step are the ones
+        :meth:`order` ranked (``all_pri`` is the same set, scheduler.py:1337-1338)."""
         n = len(all_pri)
         if n == 0:
             return
-        ran_ids = {id(r) for r in running_this_step}
-        st = np.empty((3, n), np.int32)
-        ran = np.zeros(n, np.uint8)
-        for i, r in enumerate(all_pri):
-            st[0, i] = r.pri; st[1, i] = r.idle; st[2, i] = r.runs
-            ran[i] = id(r) in ran_ids
-        dev = torch.from_numpy(st).to(self.device)
-        age_update(torch.from_numpy(ran).to(self.device), dev[0], dev[1], dev[2])
-        st = dev.cpu().numpy()
-        for i, r in enumerate(all_pri):
+        if n != self._n_members or self._members_dev is None:
+            n = self._collect_members(all_pri)
+            self._members_dev, self._n_members = self._members.upload(n), n
+        ran = running_this_step if isinstance(running_this_step, (list, tuple)) else list(running_this_step)
+        k = len(ran)
+        self._ran.ensure(max(k, 1))
+        if k:
+            a = np.fromiter(map(self._get_slot, ran), np.int32, k)
+            a.sort()
+            self._ran.np[:k] = a
+        q = self.queue
+        q.age(members=self._members_dev, ran_slots=self._ran.upload(k))
+        if self.mirror_host:
+            self.sync_host(all_pri)
+
+    def sync_host(self, reqs: Sequence) -> None:
+        """Refresh ``pri / idle / runs`` of the request objects from their device slots."""
+        n = len(reqs)
+        if n == 0:
+            return
+        idx = torch.from_numpy(np.fromiter(map(self._get_slot, reqs), np.int64, n)).to(self.device)
+        q = self.queue
+        st = torch.stack([q._pri[idx], q._idle[idx], q._runs[idx]]).cpu().numpy()
+        for i, r in enumerate(reqs):
             r.pri = int(st[0, i]); r.idle = int(st[1, i]); r.runs = int(st[2, i])
 
     # ---- front half of _general_schedule: budget walk + eviction choice -----------------------
     def plan_step(self, ordered: Sequence, new_tokens: Sequence[int], new_seqs: Sequence[int], token_budget: int,
-                  max_num_seqs: int, blocks: Optional[dict] = None) -> dict:
+                  max_num_seqs: int, blocks: Optional[dict] = None, chunkable: Optional[Sequence[int]] = None) -> dict:
         """What ``_general_schedule`` decides between the sort and the block-table updates
         (scheduler.py:1137-1218): the prefix of ``ordered`` the budget walk selects with the tokens
         granted to each request, and - when ``blocks`` describes the KV-block state - the requests
@@ -215,6 +373,8 @@ class MI355XRanker:
         ordered       the ranked list (``ordered_requests``)
         new_tokens    per element: un-chunked ``_get_num_new_tokens`` (:1878-1881)
         new_seqs      per element: ``get_max_num_running_seqs()``
+        chunkable     per element: 1 iff the group has ONE sequence in the walked status (``len(seqs) == 1``,
+                      :1884; a WAITING prompt with best_of > 1 is chunkable).  None: ``new_seqs <= 1``.
         blocks        None, or dict(state=, phys=, logical=, nrun=, nswap=, free=, watermark=) with
                       per-element sequences and the block manager's two scalars
 
@@ -229,7 +389,8 @@ class MI355XRanker:
         i32 = lambda a: torch.from_numpy(np.asarray(a, np.int32)).to(dev)
         perm = torch.arange(n, dtype=torch.int32, device=dev)       # `ordered` is already in rank order
         nt, nq = i32(new_tokens), i32(new_seqs)
-        n_sel, _, granted = budget_prefix(perm, nt, nq, token_budget, max_num_seqs, want_ran=False)
+        ck = None if chunkable is None else torch.from_numpy(np.asarray(chunkable, np.uint8)).to(dev)
+        n_sel, _, granted = budget_prefix(perm, nt, nq, token_budget, max_num_seqs, want_ran=False, chunkable=ck)
         if blocks is None:
             k = int(n_sel.item())
             g = granted[:k].cpu().numpy()
@@ -251,13 +412,21 @@ class MI355XRanker:
     # ---- wiring ------------------------------------------------------------------------------
     def install(self, scheduler) -> None:
         """Put this ranker where llm_engine.py:228-242 puts the AUXLLM and where
-        scheduler.py:325-329 binds the ordering function."""
+        scheduler.py:319-329 binds the schedule / ordering functions of a score-ordered policy."""
+        policy = self.st.policy
+        if not self.st.need_score:
+            raise ValueError(f"schedule type {self.st.raw!r} orders without a predictor score (scheduler.py:292-311): "
+                             "nothing for the ranker to do - keep the scheduler's own ordering function")
+        if policy == "xpt" and self.xpt_distribution is None:
+            self.xpt_distribution = getattr(scheduler, "distribution", None)     # what scheduler.py:312 loaded
+            if self.xpt_distribution is None:
+                raise ValueError("schedule type xpt needs its score -> length table: name it in the string "
+                                 "(xpt{path}..., scheduler.py:312) or pass xpt_distribution=(key, value)")
         scheduler.aux_model = self
         scheduler.need_score = True
         scheduler.starv = self.st.starv
         if self.st.starv != -1:
             scheduler.period = self.st.period
-        policy = self.st.policy if self.st.policy in ("opt", "tpt", "xpt") else "opt"
-        if policy == "xpt" and self.xpt_distribution is None:
-            raise ValueError("schedule type xpt needs xpt_distribution=(key, value) (scheduler.py:312)")
+        if hasattr(scheduler, "_general_schedule"):
+            scheduler._schedule = scheduler._general_schedule                    # scheduler.py:313,320,326
         scheduler._get_ordered_requests = lambda: self.ordered_requests(scheduler, policy)

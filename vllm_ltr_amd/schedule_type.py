@@ -22,6 +22,7 @@ class ScheduleType:
     need_score: bool
     starv: int           # -1 = starvation control off (scheduler.py:270)
     period: int
+    table_path: str = ""  # xpt: the path between { and } of the string, torch.load'ed at scheduler.py:312
 
     @property
     def uses_priority_key(self) -> bool:      # scheduler.py:996 vs :998
@@ -36,7 +37,10 @@ def parse_schedule_type(schedule_type: str) -> ScheduleType:
         period = int(schedule_type[schedule_type.find("period") + len("period"):])
     for prefix, need in _POLICIES:
         if schedule_type.startswith(prefix):
-            return ScheduleType(schedule_type, prefix, need, starv, period)
+            path = ""
+            if prefix == "xpt":                                    # scheduler.py:312 (same slicing: find / rfind)
+                path = schedule_type[schedule_type.find("{") + 1:schedule_type.rfind("}")]
+            return ScheduleType(schedule_type, prefix, need, starv, period, path)
     if schedule_type.startswith("fcfs") or schedule_type in ("sjf", "ljf"):
         return ScheduleType(schedule_type, "fcfs", False, starv, period)
     raise AssertionError(f"Not Supported Schedule Type {schedule_type}")   # scheduler.py:331

@@ -18,11 +18,6 @@ from . import _lib
 from .opt_spec import OPTSpec
 
 
-def _layer_names(i: int):
-    p = f"model.decoder.layers.{i}."
-    return p
-
-
 class HipOPTScorer:
     """Owns the weight tensors (torch, device memory) and the ``ltr_handle``.
 
@@ -37,9 +32,19 @@ class HipOPTScorer:
         self.lib = _lib.load()
         self.spec = spec
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.weight_dtype = weight_dtype
         wt = torch.float16 if weight_dtype == "f16" else torch.float32
         self._tensors: List[Optional[torch.Tensor]] = []
+        for name, arr in ckpt.items():
+            if np.asarray(arr).dtype not in (np.float16, np.float32):
+                raise _lib.LtrError(f"checkpoint tensor {name} has dtype {np.asarray(arr).dtype}: only fp16 / fp32 "
+                                    "checkpoints are supported (trainer.py:213-216 saves .half())")
+            if weight_dtype == "f16" and np.asarray(arr).dtype != np.float16 and name.endswith("weight") \
+                    and "layer_norm" not in name:
+                raise _lib.LtrError(f"{name} is fp32 but weight_dtype='f16' would round it: pass weight_dtype='f32' "
+                                    "or a .half() checkpoint (the f16 path assumes the weights are EXACT in fp16)")
 
         def mat(name):        # matrices / tables in the weight dtype
             return torch.from_numpy(np.ascontiguousarray(ckpt[name])).to(self.device, wt).contiguous()
@@ -75,7 +80,10 @@ class HipOPTScorer:
                               1 if spec.do_layer_norm_before else 0,
                               _lib.LTR_W_F16 if weight_dtype == "f16" else _lib.LTR_W_F32)
         self._h = C.c_void_p()
-        _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), C.byref(self._h)), "ltr_create")
+        # the library packs the dense-layer weights on THIS stream (ordered after the uploads above, which
+        # torch issued on the same stream) and makes self.device current for its own launches
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), self._stream(), C.byref(self._h)), "ltr_create")
         if chunk_tokens:
             self.set_chunk_tokens(chunk_tokens)
         self._ws: Optional[torch.Tensor] = None
@@ -116,6 +124,11 @@ class HipOPTScorer:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def check_status(self) -> None:
+        """Synchronises the current stream and raises if a forward since the last check met a token id outside
+        the vocabulary (where the reference's F.embedding raises).  Call where scores are read."""
+        _lib.check(self.lib.ltr_status(self._h, self._stream()), "ltr_status")
+
     @staticmethod
     def pack(token_lists: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
         """Flat ids + cu_seqlens, the layout ModelRunner._prepare_prompt builds
@@ -144,6 +157,8 @@ class HipOPTScorer:
         cu_host = np.ascontiguousarray(cu_host, dtype=np.int32)
         ws = self._workspace(N, T)
         max_len = int(np.diff(cu_host).max())
+        # (the library makes the handle's device current itself; the torch context keeps the workspace
+        # allocation and the stream lookup on the same device)
         _lib.check(self.lib.ltr_score(self._h, ids_dev.data_ptr(), cu_dev.data_ptr(), cu_host.ctypes.data, N, T,
                                       max_len, out.data_ptr(),
                                       logits_out.data_ptr() if logits_out is not None else None,
@@ -161,7 +176,9 @@ class HipOPTScorer:
         cu_dev = torch.from_numpy(cu).to(self.device)
         logits = torch.empty(N, self.spec.num_labels, dtype=torch.float32, device=self.device) \
             if return_logits else None
-        s = self.score_device(ids_dev, cu_dev, cu, logits).cpu().numpy()
+        s = self.score_device(ids_dev, cu_dev, cu, logits)
+        self.check_status()
+        s = s.cpu().numpy()
         return (s, logits.cpu().numpy()) if return_logits else s
 
     def score_lists(self, token_lists: Sequence[Sequence[int]]) -> np.ndarray:
