@@ -371,3 +371,68 @@ def test_outlier_activations(dev, variant):
     rel = float(np.abs(got - want).max()) / scale
     print(f"{variant}: score range {np.abs(want).max():.2f}, max rel err {rel:.2e}")
     assert np.isfinite(got).all() and rel <= 2e-5
+
+
+@pytest.mark.parametrize("variant,expected,mode", [("st", "expected_class2", "f16"), ("sharded", "expected_class2", "f16"),
+                                                   ("rank1", "expected_rank1", "f16"), ("fp32", "expected_rank1_fp32", "f32")])
+def test_hf_written_checkpoints_through_the_hip_scorer(dev, variant, expected, mode):
+    """Directories HF itself wrote (tests/golden/hf_tiny, oracle/make_hf_fixture.py) -> load_hf_checkpoint -> HIP
+    forward: logits within 1e-4 of what HF computed (a14)."""
+    from vllm_ltr_amd._lib import LtrError
+    from vllm_ltr_amd.opt_spec import checkpoint_weight_dtype, load_hf_checkpoint
+    path = os.path.join(GOLDEN, "hf_tiny", variant)
+    spec, ckpt = load_hf_checkpoint(path)
+    assert checkpoint_weight_dtype(ckpt) == mode
+    z = np.load(os.path.join(GOLDEN, "hf_tiny", expected + ".npz"))
+    sc = _scorer(spec, ckpt, dev, mode)
+    got, logits = sc.score(z["ids"], z["cu_seqlens"], return_logits=True)
+    np.testing.assert_allclose(logits, z["logits"], atol=TOL, rtol=0)
+    if spec.num_labels == 1:
+        np.testing.assert_allclose(got, z["logits"][:, 0], atol=TOL, rtol=0)
+    if mode == "f32":
+        with pytest.raises(LtrError):                       # an fp32 checkpoint is never silently rounded to fp16
+            _scorer(spec, ckpt, dev, "f16")
+
+
+def test_out_of_vocabulary_token_id_is_reported(dev):
+    """F.embedding raises on an id outside the table (vocab_parallel_embedding.py:95-106); the asynchronous HIP path
+    flags it and the first status check / score read raises."""
+    from vllm_ltr_amd._lib import LtrError
+    spec = OPTSpec.tiny_pre_ln()
+    sc = _scorer(spec, seeded_checkpoint(spec, 8), dev, "f16")
+    ids, cu = synthetic_batch(spec, [5, 9, 3], 1)
+    good = sc.score(ids, cu)
+    for bad in (spec.vocab_size, -1, 2 ** 40):
+        ids2 = ids.copy(); ids2[7] = bad
+        with pytest.raises(LtrError, match="token id"):
+            sc.score(ids2, cu)
+    assert np.array_equal(sc.score(ids, cu), good)          # the flag is cleared by the failed check
+
+
+def test_max_len_contract(dev):
+    import ctypes as C
+    from vllm_ltr_amd import _lib
+    spec = OPTSpec.tiny_pre_ln()
+    sc = _scorer(spec, seeded_checkpoint(spec, 8), dev, "f16")
+    ids, cu = synthetic_batch(spec, [5, 9, 3], 1)
+    ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+    out = torch.empty(3, device=dev)
+    ws = sc._workspace(3, int(cu[-1]))
+    rc = sc.lib.ltr_score(sc._h, ids_d.data_ptr(), cu_d.data_ptr(), cu.ctypes.data, 3, int(cu[-1]), 8, out.data_ptr(), None,
+                          ws.data_ptr(), ws.numel(), sc._stream())
+    assert rc == -22 and b"max_len" in sc.lib.ltr_last_error()      # a 9-token request against max_len = 8
+
+
+def test_handle_of_another_device_is_usable(dev):
+    """The handle remembers its device: calls work whatever device is current.  One-GPU boxes can only
+    check that the guard leaves the current device alone."""
+    spec = OPTSpec.tiny_pre_ln()
+    sc = _scorer(spec, seeded_checkpoint(spec, 8), "cuda", "f16")     # no index: resolved to the current device
+    assert sc.device.index == torch.cuda.current_device()
+    ids, cu = synthetic_batch(spec, [5, 9, 3], 1)
+    before = torch.cuda.current_device()
+    sc.score(ids, cu)
+    assert torch.cuda.current_device() == before
+    if torch.cuda.device_count() > 1:
+        sc1 = _scorer(spec, seeded_checkpoint(spec, 8), "cuda:1", "f16")
+        assert np.array_equal(sc1.score(ids, cu), sc.score(ids, cu)) and torch.cuda.current_device() == before

@@ -167,3 +167,61 @@ def test_input_stager_and_token_cache():
         assert cu_h.tolist() == want_cu.tolist()
     ids_d, cu_d, cu_h = st.stage([])
     assert ids_d.numel() == 0 and cu_d.tolist() == [0]
+
+
+HF_TINY = os.path.join(GOLDEN, "hf_tiny")
+
+
+@pytest.mark.parametrize("variant,expected", [("st", "expected_class2"), ("sharded", "expected_class2"),
+                                              ("bin", "expected_class2"), ("rank1", "expected_rank1"),
+                                              ("fp32", "expected_rank1_fp32")])
+def test_loader_reads_what_hf_writes(variant, expected):
+    """Checkpoint directories written by HF itself (oracle/make_hf_fixture.py: ``.half().save_pretrained()`` single
+    file / sharded + index, a transformers-4-style pytorch_model.bin with ``decoder.*`` names and a stray lm_head,
+    an fp32 save) through load_hf_checkpoint; the oracle on the loaded weights reproduces HF's own logits."""
+    from oracle.opt_scorer import OracleOPTScorer
+    from vllm_ltr_amd.opt_spec import checkpoint_weight_dtype
+    spec, ckpt = load_hf_checkpoint(os.path.join(HF_TINY, variant))
+    z = np.load(os.path.join(HF_TINY, expected + ".npz"))
+    assert spec.num_labels == z["logits"].shape[1]            # st/: config.json has NO num_labels (HF default 2)
+    assert list(ckpt) == [n for n, _ in tensor_shapes(spec)]
+    want_dtype = np.float32 if variant == "fp32" else np.float16
+    assert all(v.dtype == want_dtype for v in ckpt.values())
+    assert checkpoint_weight_dtype(ckpt) == ("f32" if variant == "fp32" else "f16")
+    orc = OracleOPTScorer(spec, ckpt)
+    h = orc.hidden(z["ids"], z["cu_seqlens"]).float()
+    logits = orc.pool_head(h, __import__("torch").as_tensor(z["cu_seqlens"][1:].astype(np.int64) - 1)).numpy()
+    np.testing.assert_allclose(logits, z["logits"], atol=2e-6, rtol=0)
+    if variant in ("sharded", "bin"):                          # same weights as the single-file save
+        _, base = load_hf_checkpoint(os.path.join(HF_TINY, "st"))
+        assert all(np.array_equal(ckpt[k], base[k]) for k in base)
+
+
+def test_loader_refuses_other_dtypes_and_broken_dirs(tmp_path):
+    import torch
+    from safetensors.torch import load_file, save_file
+    src = os.path.join(HF_TINY, "rank1")
+    sd = load_file(os.path.join(src, "model.safetensors"))
+    d = tmp_path / "bf16"
+    d.mkdir()
+    (d / "config.json").write_text(open(os.path.join(src, "config.json")).read())
+    save_file({k: v.to(torch.bfloat16) for k, v in sd.items()}, str(d / "model.safetensors"))
+    with pytest.raises(ValueError, match="dtype"):
+        load_hf_checkpoint(str(d))                              # no silent astype(float16)
+    e = tmp_path / "empty"
+    e.mkdir()
+    (e / "config.json").write_text(open(os.path.join(src, "config.json")).read())
+    with pytest.raises(FileNotFoundError):
+        load_hf_checkpoint(str(e))
+    m = tmp_path / "missing"
+    m.mkdir()
+    (m / "config.json").write_text(open(os.path.join(src, "config.json")).read())
+    save_file({k: v for k, v in sd.items() if "layers.1.fc2" not in k}, str(m / "model.safetensors"))
+    with pytest.raises(KeyError):
+        load_hf_checkpoint(str(m))
+
+
+def test_schedule_type_xpt_table_path():
+    st = parse_schedule_type("xpt{/data/dist/table.pt}-whatever")           # scheduler.py:312 slicing
+    assert st.policy == "xpt" and st.need_score and st.table_path == "/data/dist/table.pt"
+    assert parse_schedule_type("opt-starv3-period2").table_path == ""

@@ -77,7 +77,12 @@ class OPTSpec:
                        num_labels=num_labels)
 
     @staticmethod
-    def from_hf_config(cfg: dict) -> "OPTSpec":
+    def from_hf_config(cfg: dict, num_labels: int = 0) -> "OPTSpec":
+        """``num_labels``: rows of ``score.weight`` when known.  ``save_pretrained`` OMITS ``num_labels`` and
+        ``id2label`` from config.json when they equal HF's default of two labels, so without the checkpoint the
+        fallback is ``num_labels`` -> ``len(id2label)`` -> 2 (PretrainedConfig's default)."""
+        if not num_labels:
+            num_labels = cfg.get("num_labels") or (len(cfg["id2label"]) if cfg.get("id2label") else 2)
         return OPTSpec(
             vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
             ffn_dim=cfg["ffn_dim"], num_hidden_layers=cfg["num_hidden_layers"],
@@ -85,7 +90,7 @@ class OPTSpec:
             word_embed_proj_dim=cfg.get("word_embed_proj_dim", cfg["hidden_size"]),
             max_position_embeddings=cfg.get("max_position_embeddings", 2048),
             do_layer_norm_before=cfg.get("do_layer_norm_before", True),
-            num_labels=cfg.get("num_labels", len(cfg.get("id2label", {0: 0}))))
+            num_labels=int(num_labels))
 
     def to_hf_config_kwargs(self) -> dict:
         return dict(vocab_size=self.vocab_size, hidden_size=self.hidden_size,
@@ -150,30 +155,67 @@ def seeded_checkpoint(spec: OPTSpec, seed: int = 0, std: float = 0.02,
     return out
 
 
+def _read_hf_tensors(path: str) -> Dict[str, "np.ndarray"]:
+    """Every tensor of an HF checkpoint directory, as torch writes them: ``model.safetensors``, sharded
+    ``model-0000x-of-0000y.safetensors`` + ``model.safetensors.index.json``, ``pytorch_model.bin``, or sharded
+    ``pytorch_model-*.bin`` + ``pytorch_model.bin.index.json`` (model_loader/weight_utils.py of the reference
+    iterates the same file set)."""
+    import torch
+    files = []
+    for index, single in (("model.safetensors.index.json", "model.safetensors"),
+                          ("pytorch_model.bin.index.json", "pytorch_model.bin")):
+        if os.path.exists(os.path.join(path, index)):
+            with open(os.path.join(path, index)) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+            break
+        if os.path.exists(os.path.join(path, single)):
+            files = [single]
+            break
+    if not files:
+        raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin (or their index.json) found")
+    raw = {}
+    for fn in files:
+        fp = os.path.join(path, fn)
+        if fn.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            part = load_file(fp)
+        else:
+            part = torch.load(fp, map_location="cpu", weights_only=True)
+        for k, v in part.items():
+            if k in raw:
+                raise ValueError(f"{path}: tensor {k} appears in more than one shard")
+            raw[k] = v
+    out = {}
+    for k, v in raw.items():
+        if v.dtype not in (torch.float16, torch.float32):
+            # the f16 path relies on the weights being EXACT in fp16 and the f32 path on exact f32: a silent cast of
+            # bf16 / f64 would change the scores
+            raise ValueError(f"{path}: tensor {k} has dtype {v.dtype}; only fp16 (trainer.py:213-216 saves .half()) "
+                             "and fp32 checkpoints are supported - convert explicitly")
+        out[k] = v.contiguous().numpy()
+    return out
+
+
 def load_hf_checkpoint(path: str) -> Tuple[OPTSpec, Dict[str, np.ndarray]]:
-    """Read an HF ``OPTForSequenceClassification`` directory (config.json +
-    model.safetensors or pytorch_model.bin), the format train/trainer.py:213-216
-    writes and model_loader/loader.py:114-243 reads.  Names are normalised the
-    way opt.py:424-427 does (``decoder.*`` -> ``model.decoder.*``; ``lm_head``
-    skipped).  Returned arrays are fp16."""
+    """Read an HF ``OPTForSequenceClassification`` directory - the format train/trainer.py:213-216 writes and
+    model_loader/loader.py:114-243 reads: config.json + (sharded) safetensors or pytorch_model.bin.  Names are
+    normalised the way opt.py:424-427 does (``decoder.*`` -> ``model.decoder.*``; ``lm_head.weight`` skipped).
+    Returned arrays keep the checkpoint's dtype (fp16 or fp32; anything else is refused)."""
     with open(os.path.join(path, "config.json")) as f:
-        spec = OPTSpec.from_hf_config(json.load(f))
+        cfg = json.load(f)
     tensors: Dict[str, np.ndarray] = {}
-    st = os.path.join(path, "model.safetensors")
-    if os.path.exists(st):
-        from safetensors.numpy import load_file
-        raw = load_file(st)
-    else:
-        import torch
-        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu",
-                        weights_only=True)
-        raw = {k: v.float().numpy() for k, v in sd.items()}
-    for name, arr in raw.items():
-        if "lm_head.weight" in name:
+    for name, arr in _read_hf_tensors(path).items():
+        if "lm_head.weight" in name:                     # opt.py:421-422
             continue
-        if name.startswith("decoder."):
+        if name.startswith("decoder."):                  # opt.py:424-425
             name = "model." + name
-        tensors[name] = np.asarray(arr).astype(np.float16)
+        tensors[name] = arr
+    if "score.weight" not in tensors:
+        raise KeyError(f"checkpoint at {path} has no score.weight: not an OPTForSequenceClassification (opt.py:374)")
+    spec = OPTSpec.from_hf_config(cfg, num_labels=tensors["score.weight"].shape[0])
+    stated = cfg.get("num_labels") or (len(cfg["id2label"]) if cfg.get("id2label") else None)
+    if stated is not None and stated != spec.num_labels:
+        raise ValueError(f"{path}: config.json states {stated} labels, score.weight has {spec.num_labels} rows")
     want = dict(tensor_shapes(spec))
     missing = [n for n in want if n not in tensors]
     if missing:
@@ -182,6 +224,13 @@ def load_hf_checkpoint(path: str) -> Tuple[OPTSpec, Dict[str, np.ndarray]]:
         if tuple(tensors[n].shape) != tuple(shp):
             raise ValueError(f"{n}: shape {tensors[n].shape} != expected {shp}")
     return spec, {n: tensors[n] for n in want}
+
+
+def checkpoint_weight_dtype(ckpt: Dict[str, np.ndarray]) -> str:
+    """"f16" when every matrix / table of the checkpoint is fp16 (the ``.half()`` checkpoints of the reference's
+    trainer), else "f32" - the scorer mode that keeps the weights exact."""
+    mats = [v for k, v in ckpt.items() if np.asarray(v).ndim == 2]
+    return "f16" if all(np.asarray(v).dtype == np.float16 for v in mats) else "f32"
 
 
 def save_hf_checkpoint(path: str, spec: OPTSpec, ckpt: Dict[str, np.ndarray]) -> None:

@@ -48,7 +48,7 @@ import torch
 from . import _lib
 from .config_predictor import PrefillPredictorConfig
 from .host_pipeline import InputStager, cached_token_ids
-from .opt_spec import OPTSpec, load_hf_checkpoint
+from .opt_spec import checkpoint_weight_dtype, load_hf_checkpoint
 from .rank import DeviceQueue, RankWorkspace, budget_prefix, rank_step, reserve_select
 from .schedule_type import ScheduleType, parse_schedule_type
 from .scorer import HipOPTScorer
@@ -148,7 +148,7 @@ class MI355XRanker:
     # ---- construction from the reference's config objects ------------------------------
     @classmethod
     def from_predictor_config(cls, cfg, schedule_type: str, device: str = "cuda:0", tokenize=None,
-                              weight_dtype: str = "f16", **kw) -> "MI355XRanker":
+                              weight_dtype: str = "auto", **kw) -> "MI355XRanker":
         """``cfg``: a :class:`PrefillPredictorConfig` or a path to its JSON
         (``--prefill-predictor-model-config``, arg_utils.py:346-359).  Loads the HF
         checkpoint at ``cfg.model.path`` like llm_engine.py:228-240 does for the AUXLLM.
@@ -156,6 +156,8 @@ class MI355XRanker:
         if isinstance(cfg, (str, os.PathLike)):
             cfg = PrefillPredictorConfig.from_json(cfg)
         spec, ckpt = load_hf_checkpoint(cfg.model.path)
+        if weight_dtype == "auto":       # fp16 checkpoint (trainer.py:215) -> split-fp16 path; fp32 -> exact f32 path
+            weight_dtype = checkpoint_weight_dtype(ckpt)
         scorer = HipOPTScorer(spec, ckpt, device=device, weight_dtype=weight_dtype)
         return cls(scorer, schedule_type, max_length=cfg.model.max_length, tokenize=tokenize,
                    mtype=cfg.model.mtype, **kw)
