@@ -38,7 +38,9 @@ def parse_schedule_type(schedule_type: str) -> ScheduleType:
     for prefix, need in _POLICIES:
         if schedule_type.startswith(prefix):
             path = ""
-            if prefix == "xpt":                                    # scheduler.py:312 (same slicing: find / rfind)
+            if prefix == "xpt" and "{" in schedule_type and "}" in schedule_type:
+                # scheduler.py:312 (same slicing: find / rfind).  Without braces the reference's slice is garbage
+                # and its torch.load fails; here the path stays empty and the ranker asks for the table instead.
                 path = schedule_type[schedule_type.find("{") + 1:schedule_type.rfind("}")]
             return ScheduleType(schedule_type, prefix, need, starv, period, path)
     if schedule_type.startswith("fcfs") or schedule_type in ("sjf", "ljf"):
