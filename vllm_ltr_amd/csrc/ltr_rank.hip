@@ -24,6 +24,8 @@
 //   ltr_queue_step = rank_fused_kernel + queue_tail_kernel (budget-walk scan, ran marking,
 //                    promote/demote and aging in ONE single-workgroup launch)               2 launches
 // (round 1: prepare, count, scatter, budget_prefix, budget_mark, age_update = 6 launches).
+#include <cstdlib>
+
 #include "ltr_internal.h"
 
 namespace ltr {
@@ -68,35 +70,74 @@ __device__ __forceinline__ uint64_t key_of(const float* __restrict__ score, cons
   return make_key(score[sl], p, tiebreak ? tiebreak[i] : (uint32_t)i, flags);
 }
 
-// One launch for the whole ranking of a queue of N <= RK_BUCKET_MIN requests: a workgroup owns 64 positions,
-// rebuilds the keys of every chunk of 1024 positions from the state while staging them into LDS (4 coalesced
-// loads per key instead of one 8-byte load: ~N/64 x N x 16 B of L2 reads in total, 17 MB at 8k), counts, and
-// writes perm directly.  The state is only READ here, so workgroups never see each other's updates.
-__global__ void __launch_bounds__(256) rank_fused_kernel(
+// One launch for the whole ranking of a queue of N <= RK_BUCKET_MIN requests: a workgroup of NW waves owns 64
+// positions; every thread rebuilds keys of the chunk being staged from the state (read-only, so workgroups never
+// see each other's updates), the next chunk's keys are built in registers while the current one is counted
+// (the two dependent L2 round trips of members -> state hide behind the compares), each wave counts 1/NW of
+// the chunk for the same 64 positions, and perm is written directly.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) rank_fused_kernel(
     const float* __restrict__ score, const int32_t* __restrict__ pri, const int32_t* __restrict__ idle,
     const int32_t* __restrict__ runs, const uint32_t* __restrict__ tiebreak, const int32_t* __restrict__ members, int N,
     int starv, int period, uint32_t flags, int32_t* __restrict__ perm) {
-  __shared__ uint64_t skeys[1024];
-  __shared__ int32_t spart[256];
+  constexpr int T = NW * 64;                    // threads = keys staged per chunk
+  __shared__ uint64_t skeys[2][T];
+  __shared__ int32_t spart[T];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const uint64_t ki = (i < N) ? key_of(score, pri, idle, runs, tiebreak, members, i, starv, period, flags) : 0ull;
   int cnt = 0;
-  for (int j0 = 0; j0 < N; j0 += 1024) {
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = j0 + r * 256 + threadIdx.x;
-      skeys[r * 256 + threadIdx.x] = (j < N) ? key_of(score, pri, idle, runs, tiebreak, members, j, starv, period, flags) : ~0ull;
-    }
-    __syncthreads();
-    const uint64_t* sk = skeys + wave * 256;
+  uint64_t nxt = (threadIdx.x < N) ? key_of(score, pri, idle, runs, tiebreak, members, threadIdx.x, starv, period, flags) : ~0ull;
+  int buf = 0;
+  for (int j0 = 0; j0 < N; j0 += T, buf ^= 1) {
+    skeys[buf][threadIdx.x] = nxt;
+    __syncthreads();                            // chunk j0 is staged; the other buffer is free again
+    const int jn = j0 + T + threadIdx.x;
+    nxt = (jn < N) ? key_of(score, pri, idle, runs, tiebreak, members, jn, starv, period, flags) : ~0ull;
+    const uint64_t* sk = skeys[buf] + wave * 64;
 #pragma unroll 16
-    for (int jj = 0; jj < 256; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
+    for (int jj = 0; jj < 64; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
   }
   spart[threadIdx.x] = cnt;
   __syncthreads();
-  if (wave == 0 && i < N) perm[spart[lane] + spart[64 + lane] + spart[128 + lane] + spart[192 + lane]] = i;
+  if (wave == 0 && i < N) {
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += spart[w * 64 + lane];
+    perm[total] = i;
+  }
+}
+
+// the same count over PRECOMPUTED keys (rank_prepare_kernel): one coalesced 8-byte load per key
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) rank_count_direct_kernel(const uint64_t* __restrict__ keys, int N,
+                                                                    int32_t* __restrict__ perm) {
+  constexpr int T = NW * 64;
+  __shared__ uint64_t skeys[2][T];
+  __shared__ int32_t spart[T];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const uint64_t ki = (i < N) ? keys[i] : 0ull;
+  int cnt = 0;
+  uint64_t nxt = (threadIdx.x < N) ? keys[threadIdx.x] : ~0ull;
+  int buf = 0;
+  for (int j0 = 0; j0 < N; j0 += T, buf ^= 1) {
+    skeys[buf][threadIdx.x] = nxt;
+    __syncthreads();
+    const int jn = j0 + T + threadIdx.x;
+    nxt = (jn < N) ? keys[jn] : ~0ull;
+    const uint64_t* sk = skeys[buf] + wave * 64;
+#pragma unroll 16
+    for (int jj = 0; jj < 64; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
+  }
+  spart[threadIdx.x] = cnt;
+  __syncthreads();
+  if (wave == 0 && i < N) {
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += spart[w * 64 + lane];
+    perm[total] = i;
+  }
 }
 
 // promote/demote in place (scheduler.py:986-993), after rank_fused_kernel read the old state
@@ -335,14 +376,19 @@ struct BudgetShared {
   long long carry_tok, carry_seq;
   int first_bad;
 };
-// blocked scan over the ranked order by one workgroup of BP_THREADS threads; returns the number of
-// selected requests (uniform).  granted[] is written for the scanned positions only.
+// Blocked scan over the ranked order by one workgroup of BP_THREADS threads; returns the number of selected
+// requests (uniform).  The walk stops at the first block that holds a misfit - with max_num_seqs = 256 that is the
+// first block.  `own_block`: this thread keeps the grant of position own_block * BP_THREADS + tid in *own_grant
+// (0 when the walk stops before it or the position is not selected); granted[] itself is written here only when
+// write_granted (single-workgroup callers).
 __device__ int budget_scan(const int32_t* __restrict__ perm, const int32_t* __restrict__ new_tokens,
                            const int32_t* __restrict__ new_seqs, const uint8_t* __restrict__ chunkable, int N,
-                           long long token_budget, long long max_seqs, int32_t* __restrict__ granted, BudgetShared& sh) {
+                           long long token_budget, long long max_seqs, int32_t* __restrict__ granted, int own_block,
+                           int* own_grant, BudgetShared& sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { sh.carry_tok = 0; sh.carry_seq = 0; sh.first_bad = N; }
   __syncthreads();
+  int mine = 0;
   for (int base = 0; base < N; base += BP_THREADS) {
     int k = base + tid;
     long long t = 0, q = 0;
@@ -366,16 +412,17 @@ __device__ int budget_scan(const int32_t* __restrict__ perm, const int32_t* __re
     bool bad = (k < N) && (nt == 0 || before >= token_budget || q > max_seqs ||
                            (!chunk && t > token_budget));
     if (bad) atomicMin(&sh.first_bad, k);
-    if (k < N && granted != nullptr) {
-      long long g = token_budget - before;
-      granted[r] = (int)(chunk && g < nt ? (g > 0 ? g : 0) : nt);
-    }
+    long long g = token_budget - before;
+    const int grant = (int)(chunk && g < nt ? (g > 0 ? g : 0) : nt);
+    if (k < N && granted != nullptr) granted[r] = grant;
+    if (base == own_block * BP_THREADS) mine = grant;
     __syncthreads();
     if (tid == BP_THREADS - 1) { sh.carry_tok = t; sh.carry_seq = q; }
     __syncthreads();
     if (sh.first_bad < N) break;   // uniform: read after the barrier
   }
   __syncthreads();
+  if (own_grant) *own_grant = mine;
   return sh.first_bad;
 }
 
@@ -384,13 +431,15 @@ __global__ void __launch_bounds__(BP_THREADS) budget_prefix_kernel(
     const int32_t* __restrict__ new_seqs, const uint8_t* __restrict__ chunkable, int N, long long token_budget,
     long long max_seqs, int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran, int32_t* __restrict__ granted) {
   __shared__ BudgetShared sh;
-  const int nsel = budget_scan(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_seqs, granted, sh);
+  const int nsel = budget_scan(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_seqs, granted, -1, nullptr, sh);
   if (threadIdx.x == 0) *n_sel = nsel;
 }
 
-// The rest of a steady scheduler step in ONE single-workgroup launch, after the rank: budget-walk scan
-// (scheduler.py:1137-1211), ran marking, promote/demote write-back (:986-993; the rank kernel only read the
-// state) and aging (:1358-1365) of every queued request.  8k requests = 8 per thread.
+// The rest of a steady scheduler step in ONE launch, after the rank: budget-walk scan (scheduler.py:1137-1211), ran
+// marking, promote/demote write-back (:986-993, when the rank kernel only read the state) and aging (:1358-1365) of
+// every queued request.  Workgroup b owns positions [b * 1024, (b + 1) * 1024) of the ranked order; every
+// workgroup repeats the scan (it stops in the first block unless the budget exceeds it), so no workgroup waits
+// for another.
 __global__ void __launch_bounds__(BP_THREADS) queue_tail_kernel(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ members, const int32_t* __restrict__ new_tokens,
     const int32_t* __restrict__ new_seqs, const uint8_t* __restrict__ chunkable, int N, long long token_budget,
@@ -398,20 +447,22 @@ __global__ void __launch_bounds__(BP_THREADS) queue_tail_kernel(
     int32_t* __restrict__ idle, int32_t* __restrict__ runs, int32_t* __restrict__ n_sel, uint8_t* __restrict__ ran,
     int32_t* __restrict__ granted) {
   __shared__ BudgetShared sh;
-  const int nsel = budget_scan(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_seqs, granted, sh);
-  if (threadIdx.x == 0) *n_sel = nsel;
-  for (int k = threadIdx.x; k < N; k += BP_THREADS) {
-    const int r = perm[k];
-    const int sl = members ? members[r] : r;
-    const bool rn_ = k < nsel;
-    if (ran != nullptr) ran[r] = rn_ ? 1 : 0;
-    if (granted != nullptr && !rn_) granted[r] = 0;
-    if (pri != nullptr) {
-      int p = pri[sl], id = idle[sl], ru = runs[sl];
-      if (apply_promote && starv != -1) p = promote_demote(p, id, ru, starv, period);
-      if (rn_) { if (p == -1) ru -= 1; id = 0; } else { id += 1; }
-      pri[sl] = p; idle[sl] = id; runs[sl] = ru;
-    }
+  int grant = 0;
+  const int nsel = budget_scan(perm, new_tokens, new_seqs, chunkable, N, token_budget, max_seqs, nullptr,
+                               (int)blockIdx.x, &grant, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_sel = nsel;
+  const int k = blockIdx.x * BP_THREADS + threadIdx.x;
+  if (k >= N) return;
+  const int r = perm[k];
+  const int sl = members ? members[r] : r;
+  const bool rn_ = k < nsel;
+  if (ran != nullptr) ran[r] = rn_ ? 1 : 0;
+  if (granted != nullptr) granted[r] = rn_ ? grant : 0;
+  if (pri != nullptr) {
+    int p = pri[sl], id = idle[sl], ru = runs[sl];
+    if (apply_promote && starv != -1) p = promote_demote(p, id, ru, starv, period);
+    if (rn_) { if (p == -1) ru -= 1; id = 0; } else { id += 1; }
+    pri[sl] = p; idle[sl] = id; runs[sl] = ru;
   }
 }
 
@@ -582,6 +633,42 @@ int launch_rank_bucketed(const float* scores, int32_t* pri, int32_t* idle, int32
 
 }  // namespace
 
+namespace {
+
+// experiment knobs (diag only): LTR_RANK_MODE = 0 fused keys-on-the-fly (default) | 1 prepare + count;
+// LTR_RANK_NW = waves per workgroup of the counting kernel (4, 8 or 16)
+int rank_mode() { static int m = [] { const char* e = getenv("LTR_RANK_MODE"); return e ? atoi(e) : 0; }(); return m; }
+int rank_nw() { static int m = [] { const char* e = getenv("LTR_RANK_NW"); return e ? atoi(e) : 16; }(); return m; }
+
+// ranking of N <= RK_BUCKET_MIN requests; returns whether promote/demote was already applied in place
+int launch_rank_small(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
+                      const int32_t* members, int N, int starv, int period, uint32_t flags, int32_t* perm_out,
+                      void* ws, size_t ws_bytes, bool* applied, hipStream_t s) {
+  const int grid = (N + 63) / 64, nw = rank_nw();
+  if (rank_mode() == 1 && ws != nullptr && ws_bytes >= rank_workspace_bytes(N)) {
+    int64_t n64 = ((int64_t)N + 63) / 64 * 64;
+    uint64_t* keys = (uint64_t*)ws;
+    int32_t* rank = (int32_t*)((char*)ws + n64 * sizeof(uint64_t));
+    rank_prepare_kernel<<<(N + 255) / 256, 256, 0, s>>>(scores, (flags & LTR_RANK_USE_PRI) ? pri : nullptr, idle,
+                                                        runs, tiebreak, members, N, starv, period, flags, keys, rank);
+    LTR_LAUNCH_CHECK();
+    if (nw == 4) rank_count_direct_kernel<4><<<grid, 256, 0, s>>>(keys, N, perm_out);
+    else if (nw == 8) rank_count_direct_kernel<8><<<grid, 512, 0, s>>>(keys, N, perm_out);
+    else rank_count_direct_kernel<16><<<grid, 1024, 0, s>>>(keys, N, perm_out);
+    LTR_LAUNCH_CHECK();
+    *applied = true;
+    return LTR_OK;
+  }
+  if (nw == 4) rank_fused_kernel<4><<<grid, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  else if (nw == 8) rank_fused_kernel<8><<<grid, 512, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  else rank_fused_kernel<16><<<grid, 1024, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  LTR_LAUNCH_CHECK();
+  *applied = false;
+  return LTR_OK;
+}
+
+}  // namespace
+
 int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
                      const int32_t* members, int N, int starv, int period, uint32_t flags, int32_t* perm_out, void* ws,
                      size_t ws_bytes, hipStream_t s) {
@@ -591,10 +678,11 @@ int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* 
   if (N > RK_BUCKET_MIN)
     return launch_rank_bucketed(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, ws,
                                 ws_bytes, s);
-  rank_fused_kernel<<<(N + 63) / 64, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags,
-                                                  perm_out);
-  LTR_LAUNCH_CHECK();
-  if (starv != -1) {
+  bool applied = false;
+  if ((rc = launch_rank_small(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, ws, ws_bytes,
+                              &applied, s)))
+    return rc;
+  if (starv != -1 && !applied) {
     rank_apply_kernel<<<(N + 255) / 256, 256, 0, s>>>(pri, idle, runs, members, N, starv, period);
     LTR_LAUNCH_CHECK();
   }
@@ -608,21 +696,21 @@ int launch_queue_step(const float* scores, int32_t* pri, int32_t* idle, int32_t*
                       hipStream_t s) {
   int rc = check_rank_args(pri, idle, runs, starv, flags);
   if (rc) return rc;
-  int apply_promote = 1;
+  bool applied = true;
   if (N > RK_BUCKET_MIN) {
     rc = launch_rank_bucketed(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, ws,
-                              ws_bytes, s);
+                              ws_bytes, s);                 // rank_prepare_kernel writes the promote/demote
     if (rc) return rc;
-    apply_promote = 0;                                  // rank_prepare_kernel already wrote the promote/demote
   } else if (N > 0) {
-    rank_fused_kernel<<<(N + 63) / 64, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period,
-                                                    flags, perm_out);
-    LTR_LAUNCH_CHECK();
+    if ((rc = launch_rank_small(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out, ws,
+                                ws_bytes, &applied, s)))
+      return rc;
   }
-  queue_tail_kernel<<<1, BP_THREADS, 0, s>>>(perm_out, members, new_tokens, new_seqs, chunkable, N,
-                                             (long long)token_budget, (long long)max_seqs, starv, period,
-                                             apply_promote, (pri && idle && runs) ? pri : nullptr, idle, runs, n_sel, ran,
-                                             granted);
+  const int grid = N > 0 ? (N + BP_THREADS - 1) / BP_THREADS : 1;
+  queue_tail_kernel<<<grid, BP_THREADS, 0, s>>>(perm_out, members, new_tokens, new_seqs, chunkable, N,
+                                                (long long)token_budget, (long long)max_seqs, starv, period,
+                                                applied ? 0 : 1, (pri && idle && runs) ? pri : nullptr, idle, runs,
+                                                n_sel, ran, granted);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
