@@ -50,8 +50,13 @@ struct ltr_model {
   // space as w; F32 mode: wg == w (row-major, used as is)
   void* packed = nullptr;
   std::vector<const void*> wg;
+  // LayerNorm fold (pre-LN, F16): per layer c / d vectors of the QKV and fc1 GEMMs (launch_ln_fold_coeff)
+  bool ln_fold = false;
+  float* fold = nullptr;
+  std::vector<const float*> fold_c_qkv, fold_d_qkv, fold_c_fc1, fold_d_fc1;
   ~ltr_model() {
     if (packed) (void)hipFree(packed);
+    if (fold) (void)hipFree(fold);
     if (err_flag) (void)hipFree(err_flag);
     for (auto& r : prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (auto& e : prof_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -90,10 +95,15 @@ struct Workspace {
   AOp qkv;         // [Tc, 3H]: f32 (F32 mode) or fp16 hi|lo planes written by the QKV GEMM epilogue
   AOp f;           // operand [Tc, F]  ReLU(fc1)
   int32_t* blk;    // attention work list: int32 [Nc + 4] prefix + int4 [Tc / 64 + Nc + 1] block descriptors
+  // LayerNorm fold: second operand buffer (out_proj reads `a` while it writes the fc1 operand) and the row-piece
+  // statistics written by fc2 (for the next layer's LN1) / out_proj (for LN2): float2 [H / 64][Tc] each
+  AOp a2;
+  void* stats1;
+  void* stats2;
   size_t bytes;
 };
 
-Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base) {
+Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, bool ln_fold = false) {
   const size_t H = d.hidden_size, F = d.ffn_dim;
   const size_t esz = 4;   // operand bytes per element: f32, or fp16 hi + fp16 lo
   char* p = (char*)base;
@@ -105,6 +115,12 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base) {
   char* qkv = (char*)take(Tc * 3 * H * esz);
   char* f = (char*)take(Tc * F * esz);
   ws.blk = (int32_t*)take((Nc + 4) * 4 + (Tc / 64 + Nc + 1) * 16);
+  if (ln_fold) {
+    char* a2 = (char*)take(Tc * H * esz);
+    ws.a2 = AOp{a2, a2 ? a2 + Tc * H * 2 : nullptr};
+    ws.stats1 = take((H / 64) * Tc * 8);
+    ws.stats2 = take((H / 64) * Tc * 8);
+  }
   if (d.weight_dtype == LTR_W_F16) {
     ws.a = AOp{a, a ? a + Tc * H * 2 : nullptr};
     ws.f = AOp{f, f ? f + Tc * F * 2 : nullptr};
@@ -179,9 +195,14 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
     if ((rc = launch_to_operand(wd, ws.h, Tc, H, ws.a, s))) return rc;
   }
   const int nl = n_layers < 0 ? d.num_layers : (n_layers < d.num_layers ? n_layers : d.num_layers);
+  // LayerNorm fold (ltr_gemm.hip): out_proj / fc2 emit the operand and the row statistics of the LayerNorm that
+  // follows them, QKV / fc1 finish it in their epilogue.  `ln1_folded`: this layer's QKV operand (ws.a) and
+  // ws.stats1 were written by the previous layer's fc2.
+  const bool fold = m->ln_fold;
+  bool ln1_folded = false;
   for (int L = 0; L < nl; ++L) {
     // --- attention half (opt.py:152-163)
-    if (d.pre_ln) {
+    if (d.pre_ln && !ln1_folded) {
       rc = lnorm(Tc, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ws.a);
       if (rc) return rc;
     }
@@ -189,7 +210,8 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = ws.a; g.w = m->gemm_lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
       if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
-      g.M = Tc; g.N = 3 * H; g.K = H; g.a_slab = wd == LTR_W_F16;   // A from LayerNorm / to_operand
+      g.M = Tc; g.N = 3 * H; g.K = H; g.a_slab = wd == LTR_W_F16;   // A from LayerNorm / to_operand / the fold
+      if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L]; g.bias = m->fold_d_qkv[L]; g.ln_parts = H / 64; }
       if ((rc = gemm(g))) return rc;
     }
     {
@@ -213,10 +235,12 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       Mr = nreq;
       if ((rc = launch_gather_last_rows(wd, cu_dev + r0, t0, nreq, H, ws.h, ws.a, hb, ab, s))) return rc;
     }
+    const bool fold_here = fold;                  // also on the n_req compact rows of the pruned last layer (M = n_req)
     {
       GemmArgs g{};
       g.a = ab; g.w = m->gemm_lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
+      if (fold_here) { g.ln_gamma = (const float*)m->lw(L, LTR_WL_LN2_W); g.ln_out = ws.a2; g.ln_stats_out = ws.stats2; }
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {   // 350m: LN after the residual add; h and its operand copy
@@ -224,20 +248,23 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       if (rc) return rc;
     }
     // --- feed-forward half (opt.py:165-175)
-    if (d.pre_ln) {
+    if (d.pre_ln && !fold_here) {
       rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), nullptr, ab);
       if (rc) return rc;
     }
     {
       GemmArgs g{};
-      g.a = ab; g.w = m->gemm_lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
+      g.a = fold_here ? ws.a2 : ab; g.w = m->gemm_lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
       g.out_split = fb; g.relu = 1; g.M = Mr; g.N = F; g.K = H; g.a_slab = g.out_slab = wd == LTR_W_F16;
+      if (fold_here) { g.ln_stats_in = ws.stats2; g.ln_c = m->fold_c_fc1[L]; g.bias = m->fold_d_fc1[L]; g.ln_parts = H / 64; }
       if ((rc = gemm(g))) return rc;
     }
+    ln1_folded = fold_here && L + 1 < d.num_layers;   // the next layer's LN1 rides on this fc2
     {
       GemmArgs g{};
       g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F; g.a_slab = wd == LTR_W_F16;
+      if (ln1_folded) { g.ln_gamma = (const float*)m->lw(L + 1, LTR_WL_LN1_W); g.ln_out = ws.a; g.ln_stats_out = ws.stats1; }
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {
@@ -367,6 +394,32 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
       }
     }
   }
+  {
+    // LayerNorm fold: pre-LN blocks in F16 mode with H a multiple of 64 (LTR_NO_LN_FOLD=1 keeps the LayerNorm
+    // launches: A/B switch for measurements and debugging)
+    const char* e = getenv("LTR_NO_LN_FOLD");
+    const size_t H = desc->hidden_size, F = desc->ffn_dim;
+    m->ln_fold = desc->weight_dtype == LTR_W_F16 && desc->pre_ln && H % 64 == 0 && desc->num_layers > 0 && !(e && e[0] == '1');
+    if (m->ln_fold) {
+      const size_t per_layer = 2 * (3 * H + F);
+      if (hipMalloc((void**)&m->fold, per_layer * desc->num_layers * sizeof(float)) != hipSuccess) {
+        delete m; set_error("ltr_create: cannot allocate the LayerNorm fold vectors"); return LTR_E_NOMEM;
+      }
+      for (int L = 0; L < desc->num_layers; ++L) {
+        float* p = m->fold + (size_t)L * per_layer;
+        m->fold_c_qkv.push_back(p); m->fold_d_qkv.push_back(p + 3 * H);
+        m->fold_c_fc1.push_back(p + 6 * H); m->fold_d_fc1.push_back(p + 6 * H + F);
+        if ((rc = launch_ln_fold_coeff(m->lw(L, LTR_WL_QKV_W), (const float*)m->lw(L, LTR_WL_LN1_W),
+                                       (const float*)m->lw(L, LTR_WL_LN1_B), (const float*)m->lw(L, LTR_WL_QKV_B),
+                                       (int)(3 * H), (int)H, p, p + 3 * H, cs)) ||
+            (rc = launch_ln_fold_coeff(m->lw(L, LTR_WL_FC1_W), (const float*)m->lw(L, LTR_WL_LN2_W),
+                                       (const float*)m->lw(L, LTR_WL_LN2_B), (const float*)m->lw(L, LTR_WL_FC1_B),
+                                       (int)F, (int)H, p + 6 * H, p + 6 * H + F, cs))) {
+          delete m; return rc;
+        }
+      }
+    }
+  }
   if (hipStreamSynchronize(cs) != hipSuccess) { delete m; set_error("ltr_create: weight packing failed"); return LTR_E_HIP; }
   *out = m;
   return LTR_OK;
@@ -404,7 +457,7 @@ size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
   if (kind == LTR_WS_SCORE && h) {
     int64_t Tc = T < chunk_cap(h) ? T : chunk_cap(h);
     int64_t Nc = N < Tc ? N : Tc;
-    return carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr).bytes;
+    return carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold).bytes;
   }
   return 0;
 }
@@ -433,7 +486,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
   }
   // chunk budget from the workspace actually provided
   int64_t Tc_cap = chunk_cap(h) < T ? chunk_cap(h) : T;
-  while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr).bytes > ws_bytes) Tc_cap /= 2;
+  while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr, h->ln_fold).bytes > ws_bytes) Tc_cap /= 2;
   int r0 = 0;
   while (r0 < N) {
     int r1 = r0;
@@ -450,7 +503,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
       return LTR_E_NOMEM;
     }
     const int t0 = cu[r0], t1 = cu[r1];
-    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace);
+    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace, h->ln_fold);
     if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
     if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
     double sum_l2 = 0.0;

@@ -21,6 +21,8 @@
 // remapped so that consecutive tiles of one XCD share the same weight panel (8 XCDs,
 // private L2s).  The F16 kernel streams operands HBM -> LDS with global_load_lds; the F32
 // kernel stages through registers.
+#include <cstdlib>
+
 #include "ltr_internal.h"
 
 namespace ltr {
@@ -40,8 +42,8 @@ constexpr int NXCD = 8;
 // shares GM activation panels (4 B/elem: hi+lo) and 96/GM weight panels through that L2,
 // instead of 96 distinct activation panels (measured 13 B/clk/CU of operand fetch was the
 // limiter with the plain M-fastest order).  Bijective for any grid size.
-constexpr int GM = 8;
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+constexpr int GM_DEFAULT = 8;
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int GM = GM_DEFAULT) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg / NXCD, r = nwg % NXCD;
   const int xcd = bid % NXCD, k = bid / NXCD;
@@ -61,6 +63,14 @@ struct Epilogue {
   void* out_lo;
   int M, N, relu;
   int a_slab, out_slab;   // F16 kernel: slab-major A image / slab-major split output (GemmArgs)
+  // LayerNorm folded into the GEMMs (F16 kernel, GemmArgs::ln_*; see "LayerNorm fold" below)
+  const float* ln_gamma;  // producer: gamma [N] of the LayerNorm that follows this output
+  void* ln_hi;            // producer: slab-major planes of x * gamma * LN_FOLD_SCALE
+  void* ln_lo;
+  float2* stats_out;      // producer: [N / 64][M] (mean, M2) of the 64-column pieces of every output row
+  const float2* stats_in; // consumer: [n_part][M] pieces of the rows of A
+  const float* ln_c;      // consumer: [N] LN_FOLD_SCALE * sum_k gamma_k W[n, k]   (bias then holds beta W + b)
+  int n_part;
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -139,16 +149,28 @@ __device__ unsigned long long g_timeline[8192 * 4];
 __device__ unsigned long long g_waits[8192 * 2];
 #endif
 
-__global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
+// LayerNorm fold (pre-LN blocks).  LN(x) W^T + b = rstd (x.gamma) W^T - rstd mean (gamma W^T) + (beta W^T + b): the GEMM that
+// PRODUCES the residual stream x (out_proj, fc2: LNP) also writes a' = split(x * gamma * 16) as the next GEMM's
+// slab-major operand and, per 64-column piece of every row, (mean, M2); the CONSUMER (QKV, fc1: LNC) combines the
+// pieces of its 128 rows into (mean, rstd / 16) while its first operand slab is in flight and finishes
+// v = (acc - mean c_n) rstd / 16 + d_n in the epilogue.  No LayerNorm launch, no second read of x.  The weights stay
+// the exact fp16 checkpoint values (gamma rides on the ACTIVATION side, where the hi|lo split absorbs it); the
+// power-of-two scale keeps lo = a' - hi out of the fp16 subnormals for residual streams of magnitude ~0.01.
+constexpr float LN_FOLD_SCALE = 16.f;
+enum { LN_NONE = 0, LNP = 1, LNC = 2 };
+
+template <int LNM>
+__global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
-    int K, int tiles_m, int tiles_n, Epilogue ep) {
-  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE];   // 64 KiB
+    int K, int tiles_m, int tiles_n, int gm, Epilogue ep) {
+  // 64 KiB of stages (+ 1 KiB: (mean, rstd/16) of the tile's 128 rows, LNC).  ONE array on purpose (see above).
+  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE + (LNM == LNC ? 512 : 0)];
 
 #ifdef LTR_GEMM_TIMELINE
   const unsigned long long tl0 = __builtin_readcyclecounter();
 #endif
   int tm, tn;
-  tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, gm);
   const int m0 = tm * BM, n0 = tn * BN16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,6 +231,31 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
   unsigned long long tl_dma = 0, tl_bar = 0;
 #endif
   issue(0, 0);
+  if (LNM == LNC && tid < BM) {
+    // (mean, M2) of the row's 64-column pieces -> (mean, rstd / scale).  Shifted-data sums around the first piece's
+    // mean (equal counts per piece), so the loads of all pieces are independent of each other and fly together:
+    // a serial Chan update would put n_part dependent L2 round trips in front of the first barrier of the tile.
+    const int row = min(m0 + tid, M - 1);
+    const float2* sp = ep.stats_in + row;
+    const float2 s0 = sp[0];
+    float s1 = 0.f, s2 = 0.f, sm = s0.y;
+    auto add = [&](const float2 s) { const float d = s.x - s0.x; s1 += d; s2 = fmaf(d, d, s2); sm += s.y; };
+    if (ep.n_part == 12) {
+      float2 v[11];
+#pragma unroll
+      for (int p = 0; p < 11; ++p) v[p] = sp[(size_t)(p + 1) * M];
+#pragma unroll
+      for (int p = 0; p < 11; ++p) add(v[p]);
+    } else {
+#pragma unroll 4
+      for (int p = 1; p < ep.n_part; ++p) add(sp[(size_t)p * M]);
+    }
+    const float np_ = (float)ep.n_part;
+    const float mean = s0.x + s1 / np_;
+    const float m2 = sm + 64.f * fmaxf(s2 - s1 * s1 / np_, 0.f);
+    const float rstd = rsqrtf(m2 / (64.f * np_) + LN_EPS);
+    reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] = make_float2(mean, rstd * (1.f / LN_FOLD_SCALE));
+  }
   for (int kt = 0; kt < nk; ++kt) {
 #ifdef LTR_GEMM_TIMELINE
     const unsigned long long w0 = __builtin_readcyclecounter();
@@ -294,6 +341,16 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
     bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
     bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
   }
+  float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;      // LNP: gamma * scale; LNC: c_n
+  if (LNM != LN_NONE && ccol < N) {
+    const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
+    lnv_a = *reinterpret_cast<const float4*>(src + ccol);
+    lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
+    if (LNM == LNP) {
+      lnv_a.x *= LN_FOLD_SCALE; lnv_a.y *= LN_FOLD_SCALE; lnv_a.z *= LN_FOLD_SCALE; lnv_a.w *= LN_FOLD_SCALE;
+      lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
@@ -337,6 +394,13 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         if (!ok[it]) continue;
+        if (LNM == LNC) {   // v = (acc - mean c_n) rstd / scale (+ d_n, held in bias)
+          const float2 st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
+          va[it].x = (va[it].x - st2.x * lnv_a.x) * st2.y; va[it].y = (va[it].y - st2.x * lnv_a.y) * st2.y;
+          va[it].z = (va[it].z - st2.x * lnv_a.z) * st2.y; va[it].w = (va[it].w - st2.x * lnv_a.w) * st2.y;
+          vb[it].x = (vb[it].x - st2.x * lnv_b.x) * st2.y; vb[it].y = (vb[it].y - st2.x * lnv_b.y) * st2.y;
+          vb[it].z = (vb[it].z - st2.x * lnv_b.z) * st2.y; vb[it].w = (vb[it].w - st2.x * lnv_b.w) * st2.y;
+        }
         float x[8] = {va[it].x + bias_a.x, va[it].y + bias_a.y, va[it].z + bias_a.z, va[it].w + bias_a.w,
                       vb[it].x + bias_b.x, vb[it].y + bias_b.y, vb[it].z + bias_b.z, vb[it].w + bias_b.w};
         if (ep.relu) {
@@ -356,6 +420,40 @@ __global__ void __launch_bounds__(512, 2) gemm_f16s_kernel(
           const size_t os = ep.out_slab ? slab_off(gr[it], ccol, M) : o[it];
           *reinterpret_cast<uint4*>((__half*)ep.out_hi + os) = *reinterpret_cast<const uint4*>(h);
           *reinterpret_cast<uint4*>((__half*)ep.out_lo + os) = *reinterpret_cast<const uint4*>(l);
+        }
+        if (LNM == LNP) {
+          // x[0..7] = columns ccol..+3 and ccol+32..+35 of the f32 row just stored (wide ownership: the 8 lanes of a
+          // row hold its 64 columns in this wave).  Operand of the next GEMM: split(x gamma scale), slab-major -
+          // per plane the 8 lanes x 8 rows of one store instruction cover 512 contiguous bytes of a slab.
+          const float gs[8] = {lnv_a.x, lnv_a.y, lnv_a.z, lnv_a.w, lnv_b.x, lnv_b.y, lnv_b.z, lnv_b.w};
+          __half h[8], l[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) split_f16(x[e] * gs[e], h[e], l[e]);
+          // lane pair (l, l ^ 1) holds columns {4k..4k+3, 32+4k..} and {4k+4..4k+7, 36+4k..}: swap halves so that the even
+          // lane owns 8 consecutive columns of the first slab and the odd lane 8 of the second -> ONE 16-byte store
+          // per plane and lane (8-byte stores issue at half the rate per byte)
+          const bool odd = lane & 1;
+          uint2 hk = *reinterpret_cast<const uint2*>(odd ? h + 4 : h), hs = *reinterpret_cast<const uint2*>(odd ? h : h + 4);
+          uint2 lk = *reinterpret_cast<const uint2*>(odd ? l + 4 : l), ls = *reinterpret_cast<const uint2*>(odd ? l : l + 4);
+          uint2 hr, lr;   // what the partner sends: its half that belongs to my slab
+          hr.x = __shfl_xor(hs.x, 1, 64); hr.y = __shfl_xor(hs.y, 1, 64);
+          lr.x = __shfl_xor(ls.x, 1, 64); lr.y = __shfl_xor(ls.y, 1, 64);
+          const uint4 hv = odd ? make_uint4(hr.x, hr.y, hk.x, hk.y) : make_uint4(hk.x, hk.y, hr.x, hr.y);
+          const uint4 lv = odd ? make_uint4(lr.x, lr.y, lk.x, lk.y) : make_uint4(lk.x, lk.y, lr.x, lr.y);
+          const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
+          const size_t oo = slab_off(gr[it], c0, M);
+          *reinterpret_cast<uint4*>((__half*)ep.ln_hi + oo) = hv;
+          *reinterpret_cast<uint4*>((__half*)ep.ln_lo + oo) = lv;
+          // (mean, M2) of this wave's 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
+          // row, so they are active exactly when this lane is)
+          float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+          const float mu = sm * (1.f / 64.f);
+          float q = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float dd = x[e] - mu; q = fmaf(dd, dd, q); }
+          q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+          if ((lane & 7) == 0) ep.stats_out[(size_t)(tn * 4 + wc) * M + gr[it]] = make_float2(mu, q);
         }
       }
     }
@@ -476,6 +574,34 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const __half* __restri
 
 }  // namespace
 
+namespace {
+// c_n = scale * sum_k gamma_k W[n, k], d_n = sum_k beta_k W[n, k] + b_n for the LayerNorm fold; one wave per output
+// row, double accumulation (one-time, at ltr_create)
+__global__ void __launch_bounds__(256) ln_fold_coeff_kernel(const __half* __restrict__ w /*[N, K] row-major*/,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ bias, int N, int K,
+                                                            float* __restrict__ c_out, float* __restrict__ d_out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  double c = 0.0, d = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const double wv = (double)__half2float(w[(size_t)n * K + k]);
+    c += (double)gamma[k] * wv;
+    d += (double)beta[k] * wv;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+  if (lane == 0) { c_out[n] = (float)(c * (double)LN_FOLD_SCALE); d_out[n] = (float)(d + (double)(bias ? bias[n] : 0.f)); }
+}
+}  // namespace
+
+int launch_ln_fold_coeff(const void* w_f16, const float* gamma, const float* beta, const float* bias, int N, int K,
+                         float* c_out, float* d_out, hipStream_t s) {
+  ln_fold_coeff_kernel<<<(N + 3) / 4, 256, 0, s>>>((const __half*)w_f16, gamma, beta, bias, N, K, c_out, d_out);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
 int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s) {
   if (K % BK16) { set_error("pack_weight: K=%d must be a multiple of %d", K, BK16); return LTR_E_INVAL; }
   const size_t pieces = (size_t)N * K / 8;
@@ -493,13 +619,35 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   }
   const int bn = wdtype == LTR_W_F16 ? BN16 : BN;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
-  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab};
+  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab,
+              g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
+              g.ln_parts};
+  const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : LN_NONE);
+  if (lnm != LN_NONE) {
+    if (wdtype != LTR_W_F16) { set_error("gemm: the LayerNorm fold exists in F16 mode only"); return LTR_E_INVAL; }
+    if (lnm == LNP && (g.out_split.hi || !g.out_f32 || !g.ln_out.hi || !g.ln_stats_out || g.N % 64)) {
+      set_error("gemm: LN producer needs an f32 output only, the operand planes, the stats buffer and N %% 64 == 0");
+      return LTR_E_INVAL;
+    }
+    if (lnm == LNC && (!g.ln_c || g.ln_parts <= 0 || g.ln_parts * 64 != g.K || !g.a_slab)) {
+      set_error("gemm: LN consumer needs c[N], K / 64 stats pieces and a slab-major A");
+      return LTR_E_INVAL;
+    }
+  }
   if (wdtype != LTR_W_F16 && (g.a_slab || g.out_slab)) { set_error("gemm: slab-major operands exist in F16 mode only"); return LTR_E_INVAL; }
   if (g.out_slab && g.N % 32) { set_error("gemm: slab-major output needs N %% 32 == 0"); return LTR_E_INVAL; }
   dim3 grid(tiles_m * tiles_n);
   if (wdtype == LTR_W_F16) {
-    gemm_f16s_kernel<<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
-                                          g.N, g.K, tiles_m, tiles_n, ep);
+    static const int gm = [] { const char* e = getenv("LTR_GEMM_GM"); return e ? atoi(e) : GM_DEFAULT; }();   // diag knob
+    if (lnm == LNP)
+      gemm_f16s_kernel<LNP><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
+                                                 g.N, g.K, tiles_m, tiles_n, gm, ep);
+    else if (lnm == LNC)
+      gemm_f16s_kernel<LNC><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
+                                                 g.N, g.K, tiles_m, tiles_n, gm, ep);
+    else
+      gemm_f16s_kernel<LN_NONE><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
+                                                     g.N, g.K, tiles_m, tiles_n, gm, ep);
   } else {
     gemm_f32_kernel<<<grid, 256, 0, s>>>((const float*)g.a.hi, (const float*)g.w, g.M, g.N, g.K, tiles_m, tiles_n,
                                          ep);

@@ -60,11 +60,23 @@ struct GemmArgs {
   // halves (every 32-wide K-slab of a 16-row group is 1 KiB of contiguous memory for the LDS DMA).
   int a_slab;            // A planes are slab-major (written by launch_layernorm / launch_to_operand / a GEMM with out_slab)
   int out_slab;          // write out_split slab-major (it is the next GEMM's A operand)
+  // LayerNorm folded into the GEMMs (F16 mode, pre-LN blocks; ltr_gemm.hip "LayerNorm fold").
+  // Producer (the GEMM whose f32 output is the residual stream the next LayerNorm normalises):
+  const float* ln_gamma = nullptr;   // [N] gamma of that LayerNorm; non-null selects the producer epilogue
+  AOp ln_out{nullptr, nullptr};      // slab-major planes of out * gamma * 16: the next GEMM's A operand
+  void* ln_stats_out = nullptr;      // float2 [N / 64][M]: (mean, M2) of every 64-column piece of every row
+  // Consumer (A = a producer's ln_out):
+  const void* ln_stats_in = nullptr; // float2 [K / 64][M]; non-null selects the consumer epilogue
+  const float* ln_c = nullptr;       // [N] 16 * sum_k gamma_k W[n, k]; `bias` must then hold sum_k beta_k W[n, k] + b_n
+  int ln_parts = 0;                  // K / 64
 };
 
 // launchers (each in its own .hip file)
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
 int launch_pack_weight(const void* src_f16 /*[N,K]*/, void* dst_f16 /*[K/32][N][32]*/, int N, int K, hipStream_t s);
+// c[n] = 16 * sum_k gamma_k W[n,k], d[n] = sum_k beta_k W[n,k] + bias[n]  (W row-major fp16, the checkpoint layout)
+int launch_ln_fold_coeff(const void* w_f16, const float* gamma, const float* beta, const float* bias, int N, int K,
+                         float* c_out, float* d_out, hipStream_t s);
 
 // out_op: F16 mode -> slab-major hi|lo image (GemmArgs::a_slab); F32 mode -> row-major f32 copy
 int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
