@@ -313,6 +313,46 @@ int ltr_listmle(const float* y_pred, const float* y_true, const int32_t* shuffle
                 float eps, float pad_value, float* loss_out, float* row_loss_out, float* grad_out,
                 void* stream);
 
+/* The other half of SURVEY.md 8f-4: ONE optimisation step of the predictor's fine-tuning loop,
+ * train/trainer.py:122-165 - forward of the OPTForSequenceClassification predictor on a slate of prompts
+ * (prefill_predictor.py:76-79), loss_func(outputs.view(1, -1), labels) with listMLE / MSELoss or CrossEntropyLoss over
+ * num_labels classes (:125-157), loss.backward(), torch.optim.Adam(lr, weight_decay).step() (:122,161-165: L2 decay added
+ * to the gradient, bias-corrected moments), optimizer.zero_grad().  All arithmetic is f32 (fp32 master weights, :99-101).
+ * ltr_train_create COPIES the f32 weights (same pointer order as ltr_create, every tensor f32) into library-owned
+ * parameter / gradient / moment buffers; ltr_train_read copies the current value of a tensor out, for evaluation and
+ * for writing the fine-tuned checkpoint (trainer.py:213-216 saves it .half()). */
+enum { LTR_LOSS_LISTMLE = 0, LTR_LOSS_MSE = 1, LTR_LOSS_CROSSENTROPY = 2 };
+typedef struct ltr_train_config {
+  float lr;            /* trainer.py --lr (2e-5) */
+  float beta1, beta2;  /* torch.optim.Adam defaults 0.9, 0.999 */
+  float eps;           /* 1e-8 */
+  float weight_decay;  /* trainer.py --wc (0.01) */
+  int32_t loss;        /* LTR_LOSS_* (trainer.py --loss) */
+  float listmle_eps;   /* allrank DEFAULT_EPS 1e-10 */
+  float pad_value;     /* allrank PADDED_Y_VALUE -1 */
+  float dropout;       /* HF OPT config.dropout (0.1 in train mode) after out_proj and fc2; 0 disables.  Masks come from
+                          a counter-based hash of (seed, step, layer, site, element) - torch's RNG stream cannot be matched */
+  uint64_t seed;
+} ltr_train_config;
+typedef struct ltr_trainer* ltr_train_handle;
+int ltr_train_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights,
+                     const ltr_train_config* cfg, void* stream, ltr_train_handle* out);
+int ltr_train_destroy(ltr_train_handle h);
+size_t ltr_train_workspace_bytes(ltr_train_handle h, int64_t N, int64_t T);
+/* One step on a slate of N prompts (flat ids / cu_seqlens as ltr_score; the whole slate is one pass).
+ *   labels   f32 [N]: listMLE / mse targets, or class indices for crossentropy
+ *   shuffle  int32 [N]: the random permutation of listMLE.py:33 (listMLE only)
+ *   apply_update 0: gradients only (ltr_train_grad), no Adam step
+ *   loss_out f32 [1] (device); logits_out f32 [N, num_labels] or NULL: the outputs BEFORE the update */
+int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
+                   const int32_t* cu_seqlens_host, int32_t N, int32_t T, const float* labels,
+                   const int32_t* shuffle, int32_t apply_update, float* loss_out, float* logits_out,
+                   void* workspace, size_t ws_bytes, void* stream);
+/* Copies parameter (what = 0) or gradient (what = 1) tensor `index` (ltr_create's index space; QKV stacked) into
+ * dst (device, f32, `capacity` floats) on `stream`; *count_out = its element count (dst NULL: size query). */
+int ltr_train_read(ltr_train_handle h, int32_t index, int32_t what, float* dst, size_t capacity,
+                   size_t* count_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

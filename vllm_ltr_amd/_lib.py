@@ -23,7 +23,8 @@ SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "lt
            "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
-           "ltr_status", "ltr_queue_step")
+           "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
+           "ltr_train_step", "ltr_train_read")
 ABI_VERSION = 2
 
 
@@ -44,6 +45,15 @@ class HeadDesc(C.Structure):
 
 
 ACTIVATIONS = {None: 0, "Identity": 0, "ReLU": 1, "Sigmoid": 2, "Tanh": 3, "GELU": 4, "SiLU": 5}
+
+
+class TrainConfig(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("loss", C.c_int32), ("listmle_eps", C.c_float), ("pad_value", C.c_float),
+                ("dropout", C.c_float), ("seed", C.c_uint64)]
+
+
+LOSSES = {"listMLE": 0, "mse": 1, "crossentropy": 2}
 
 
 class ProfileStats(C.Structure):
@@ -101,9 +111,15 @@ def _load() -> C.CDLL:
     lib.ltr_head_create.argtypes = [C.POINTER(HeadDesc), C.POINTER(vp), i32, C.POINTER(vp)]
     lib.ltr_head_destroy.argtypes = [vp]
     lib.ltr_head_score.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.ltr_train_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp), i32, C.POINTER(TrainConfig), vp, C.POINTER(vp)]
+    lib.ltr_train_destroy.argtypes = [vp]
+    lib.ltr_train_workspace_bytes.argtypes = [vp, i64, i64]
+    lib.ltr_train_workspace_bytes.restype = sz
+    lib.ltr_train_step.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]
+    lib.ltr_train_read.argtypes = [vp, i32, i32, vp, sz, C.POINTER(sz), vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version"):
+        if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version", "ltr_train_workspace_bytes"):
             fn.restype = C.c_int
     if lib.ltr_abi_version() != ABI_VERSION:
         raise LtrError(f"{LIB_PATH} has ABI version {lib.ltr_abi_version()}, this binding needs {ABI_VERSION}: rebuild")

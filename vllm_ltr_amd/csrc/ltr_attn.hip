@@ -82,7 +82,8 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(64) attn_f32_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                       const int32_t* __restrict__ blk_start,
                                                       const int4* __restrict__ blk_desc, int n_req, int H,
-                                                      float scale_log2e, void* out_hi, void* out_lo) {
+                                                      float scale_log2e, void* out_hi, void* out_lo,
+                                                      float* __restrict__ lse2 /*nullable: [T, heads] m + log2(l)*/) {
   __shared__ __attribute__((aligned(16))) float s_k[KT * D];
   __shared__ __attribute__((aligned(16))) float s_v[KT * D];
   const int b = blockIdx.x;
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(64) attn_f32_kernel(const float* __restrict__ 
   if (!valid) return;
   const float inv = 1.f / l;
   const size_t ob = (size_t)(t0 + qi) * H + head * D;
+  if (lse2 != nullptr) lse2[(size_t)(t0 + qi) * (H / D) + head] = m + log2f(l);   // training: softmax is recomputed in the backward
   if (SPLIT) {
     __half* ph = (__half*)out_hi + ob;
     __half* pl = (__half*)out_lo + ob;
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
 }  // namespace
 
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
-                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s) {
+                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2) {
   if (n_req == 0 || T == 0) return LTR_OK;
   if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
   const float scale_log2e = 0.125f * 1.4426950408889634f;   // d^-0.5 (opt.py:73) * log2(e)
@@ -429,10 +431,10 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
     dim3 grid(T / QB + n_req, n_heads);
     if (wdtype == LTR_W_F32)
       attn_f32_kernel<false><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, blk_desc, n_req, H, scale_log2e,
-                                                 out.hi, out.lo);
+                                                 out.hi, out.lo, lse2);
     else   // debug A/B (wdtype -1): f32 VALU attention feeding split operands
       attn_f32_kernel<true><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, blk_desc, n_req, H, scale_log2e,
-                                                out.hi, out.lo);
+                                                out.hi, out.lo, nullptr);
   }
   LTR_LAUNCH_CHECK();
   return LTR_OK;

@@ -94,7 +94,8 @@ int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N
 // in the F16 mode), writes operand [T, H]
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req,
                      int T, int H, int n_heads, int32_t* blk_start /*scratch: (n_req+4)*4 + (T/64+n_req+1)*16 bytes*/, AOp out,
-                     int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s);
+                     int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s,
+                     float* lse2 = nullptr /*F32 mode: [T, heads] log2-domain log-sum-exp of every query row (training)*/);
 
 int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu /*nullptr: rows are already compact*/, int tok_off,
                      int N, int H, int De,

@@ -1,0 +1,837 @@
+// One optimisation step of the predictor's fine-tuning loop on gfx950.
+//
+// Reference: train/trainer.py:122-165 - fp32 master weights (set_default_torch_dtype(float32), :99-101),
+// `outputs = predictor(input_ids, attention_mask)` (HF OPTForSequenceClassification, prefill_predictor.py:76-79),
+// `loss_func(outputs.view(1, -1), labels)` with listMLE / MSELoss, or CrossEntropyLoss over num_labels classes
+// (:125-157), `loss.backward()`, `torch.optim.Adam(lr, weight_decay).step()` (:122,161-165).
+//
+// Everything is f32 (the reference computes the forward under autocast = fp16 on its GPU; f32 is at least that
+// precise, and what the CPU oracle - torch autograd over the scorer's arithmetic - computes).  The dense layers run on
+// the exact-f32 MFMA GEMM (gemm_f32_kernel, C = A B^T); the backward's dX = dY W and dW = dY^T X are brought to that
+// form with explicit transposes.  Attention, LayerNorm, ReLU, losses, Adam: VALU kernels below.  Training batches are
+// slates of tens of prompts (trainer.py --batch-size 64), so this file is written for clarity and exactness, not for
+// the ranking path's throughput.
+//
+// Differences to the reference's recipe, on purpose:
+//  * dropout: HF OPT applies dropout(0.1) after out_proj and fc2 in train mode; its masks come from torch's global
+//    RNG and cannot be reproduced by another implementation.  ltr_train_config.dropout applies the same two dropouts
+//    with a counter-based hash of (seed, step, layer, site, element); 0 (the default, and what the parity fixtures
+//    use) disables it.
+//  * atomics: the embedding-table gradients are accumulated with f32 atomics (duplicate token ids / positions), so
+//    their last bits depend on arrival order; every other reduction runs in a fixed order.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "ltr_internal.h"
+
+namespace ltr {
+namespace {
+
+constexpr int D = 64;   // head size
+
+// ------------------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------------------
+// out[c * Rp + r] = in[r * C + c]; columns R..Rp-1 of every output row are zero (the GEMM's K must be a multiple of 16)
+__global__ void __launch_bounds__(256) transpose_pad_kernel(const float* __restrict__ in, int R, int C, int Rp,
+                                                            float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int k = 0; k < 32; k += 8) {
+    const int r = r0 + ty + k, c = c0 + tx;
+    tile[ty + k][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = 0; k < 32; k += 8) {
+    const int c = c0 + ty + k, r = r0 + tx;
+    if (c < C && r < Rp) out[(size_t)c * Rp + r] = tile[tx][ty + k];
+  }
+}
+
+// column sums in two fixed-order stages: partial[b][c] = sum over rows [b * 256, ...) ; out[c] = sum_b partial[b][c]
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y /*nullable: sums x*y*/,
+                                                             int M, int N, float* __restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += y ? x[(size_t)r * N + c] * y[(size_t)r * N + c] : x[(size_t)r * N + c];
+  partial[(size_t)blockIdx.y * N + c] = s;
+}
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nb, int N,
+                                                           float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += partial[(size_t)b * N + c];
+  out[c] = s;
+}
+
+// LayerNorm backward, one wave per row: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;
+// dx_out = (base ? base : 0) + dx; xhat_dy = dy * xhat (its column sums are dgamma; dbeta = column sums of dy)
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, const float* base, int M, int H,
+                                                     float* dx_out, float* __restrict__ xhat_dy) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * H;
+  const float* dr = dy + (size_t)row * H;
+  float s = 0.f;
+  for (int c = lane; c < H; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+  for (int c = lane; c < H; c += 64) { const float d = xr[c] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + LN_EPS);
+  float sg = 0.f, sgx = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+    sg += g; sgx += g * xh;
+  }
+  const float mg = wave_sum(sg) / (float)H, mgx = wave_sum(sgx) / (float)H;
+  for (int c = lane; c < H; c += 64) {
+    const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+    const float dx = rstd * (g - mg - xh * mgx);
+    const size_t o = (size_t)row * H + c;
+    xhat_dy[o] = dr[c] * xh;
+    dx_out[o] = (base ? base[o] : 0.f) + dx;
+  }
+}
+
+__global__ void __launch_bounds__(256) relu_bwd_kernel(float* __restrict__ df, const float* __restrict__ f, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    if (!(f[i] > 0.f)) df[i] = 0.f;
+}
+
+// counter-based dropout mask: keep with probability 1 - p, scale by 1 / (1 - p)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.f / 16777216.f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}
+// y = base + dropout(x)   (forward: base = residual; backward: x = dout, base = nullptr)
+__global__ void __launch_bounds__(256) dropout_add_kernel(const float* __restrict__ x, const float* base, float* y, size_t n,
+                                                          uint64_t seed, float p) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = (base ? base[i] : 0.f) + x[i] * dropout_scale(seed, i, p);
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ cu,
+                                                          int n_req, int H, float* __restrict__ dst) {
+  const int r = blockIdx.x;
+  if (r >= n_req) return;
+  const size_t s = (size_t)(cu[r + 1] - 1) * H;
+  for (int c = threadIdx.x; c < H; c += 256) dst[(size_t)r * H + c] = src[s + c];
+}
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ cu,
+                                                           int n_req, int H, float* __restrict__ dst) {
+  const int r = blockIdx.x;
+  if (r >= n_req) return;
+  const size_t s = (size_t)(cu[r + 1] - 1) * H;
+  for (int c = threadIdx.x; c < H; c += 256) dst[s + c] = src[(size_t)r * H + c];
+}
+
+// logits[r, j] = y[r, :] . Ws[j, :]     one wave per (row, label)
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ ws, int N, int De,
+                                                       int nl, float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long long)N * nl) return;
+  const int r = (int)(w / nl), j = (int)(w % nl);
+  float s = 0.f;
+  for (int c = lane; c < De; c += 64) s += y[(size_t)r * De + c] * ws[(size_t)j * De + c];
+  s = wave_sum(s);
+  if (lane == 0) logits[w] = s;
+}
+// dy[r, c] = sum_j dl[r, j] Ws[j, c];  dWs[j, c] = sum_r dl[r, j] y[r, c]   (fixed order over j / r)
+__global__ void __launch_bounds__(256) head_bwd_dy_kernel(const float* __restrict__ dl, const float* __restrict__ ws, int N, int De,
+                                                          int nl, float* __restrict__ dy) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)N * De) return;
+  const int r = (int)(i / De), c = (int)(i % De);
+  float s = 0.f;
+  for (int j = 0; j < nl; ++j) s += dl[(size_t)r * nl + j] * ws[(size_t)j * De + c];
+  dy[i] = s;
+}
+__global__ void __launch_bounds__(256) head_bwd_dw_kernel(const float* __restrict__ dl, const float* __restrict__ y, int N, int De,
+                                                          int nl, float* __restrict__ dws) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)nl * De) return;
+  const int j = (int)(i / De), c = (int)(i % De);
+  float s = 0.f;
+  for (int r = 0; r < N; ++r) s += dl[(size_t)r * nl + j] * y[(size_t)r * De + c];
+  dws[i] = s;
+}
+
+// MSELoss (mean over the N outputs) and its gradient; single workgroup, fixed order
+__global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ o, const float* __restrict__ y, int N,
+                                                  float* __restrict__ loss, float* __restrict__ dl) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) { const float d = o[i] - y[i]; s += d * d; dl[i] = 2.f * d / (float)N; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int k = 0; k < 256; ++k) t += red[k]; *loss = t / (float)N; }
+}
+// CrossEntropyLoss (mean over rows): one wave per row writes row_loss and dl; a second kernel averages
+__global__ void __launch_bounds__(256) ce_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels, int N,
+                                                      int nl, float* __restrict__ row_loss, float* __restrict__ dl) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= N) return;
+  const float* lr = logits + (size_t)r * nl;
+  float mx = -INFINITY;
+  for (int j = lane; j < nl; j += 64) mx = fmaxf(mx, lr[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < nl; j += 64) s += expf(lr[j] - mx);
+  s = wave_sum(s);
+  const int lab = (int)labels[r];
+  for (int j = lane; j < nl; j += 64) dl[(size_t)r * nl + j] = (expf(lr[j] - mx) / s - (j == lab ? 1.f : 0.f)) / (float)N;
+  if (lane == 0) row_loss[r] = logf(s) + mx - lr[lab];
+}
+__global__ void __launch_bounds__(64) mean_kernel(const float* __restrict__ v, int N, float* __restrict__ out) {
+  if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < N; ++i) s += v[i]; *out = s / (float)N; }
+}
+
+// embedding backward: dE_pos[pos + 2] += dh0[t]; dE_tok[id] += dtok[t]   (duplicates -> atomics)
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ cu, int n_req,
+                                                        int T, const float* __restrict__ dh0, const float* __restrict__ dtok,
+                                                        int H, int De, int vocab, int pos_rows, float* __restrict__ g_pos,
+                                                        float* __restrict__ g_tok) {
+  const int t = blockIdx.x;
+  if (t >= T) return;
+  const int req = find_request(cu, n_req, t);
+  const int pos = min(t - cu[req] + 2, pos_rows - 1);
+  long long id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&g_pos[(size_t)pos * H + c], dh0[(size_t)t * H + c]);
+  for (int c = threadIdx.x; c < De; c += 256) atomicAdd(&g_tok[(size_t)id * De + c], dtok[(size_t)t * De + c]);
+}
+
+// torch.optim.Adam with L2 weight decay: g += wd p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr (m / bc1) / (sqrt(v / bc2) + eps)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float pi = p[i];
+    const float gi = g[i] + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - lr * (mi / bc1) / (sqrtf(vi) / sqrtf(bc2) + eps);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention backward (f32 VALU).  Forward (attn_f32_kernel): S2 = (q scale log2e) . k, P = exp2(S2 - lse2), O = P V.
+// With D_q = sum_d dO O:  dV_k = sum_q P dO;  dS = P (dO . V_k - D_q);  dQ = scale sum_k dS K;  dK = scale sum_q dS Q.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BQ = 64;    // rows per block of the work list (attn_blocks_kernel with qb = 64)
+constexpr int BT = 32;    // rows staged in LDS per step
+
+// one lane per query: dQ and D
+__global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                         const float* __restrict__ dout, const float* __restrict__ lse2,
+                                                         const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc,
+                                                         int n_req, int H, float scale, float* __restrict__ dqkv,
+                                                         float* __restrict__ Dq) {
+  __shared__ __attribute__((aligned(16))) float s_k[BT * D];
+  __shared__ __attribute__((aligned(16))) float s_v[BT * D];
+  const int b = blockIdx.x;
+  if (b >= blk_start[n_req]) return;
+  const int head = blockIdx.y, lane = threadIdx.x, nh = H / D;
+  const int4 desc = blk_desc[b];
+  const int q0 = desc.y, t0 = desc.z, L = desc.w;
+  const int qi = q0 + lane;
+  const bool valid = qi < L;
+  const size_t ld = (size_t)3 * H;
+  const float sl2 = scale * 1.4426950408889634f;
+  float q[D], dO[D], dq[D];
+  float dsum = 0.f, lse = 0.f;
+  {
+    const size_t row = (size_t)(t0 + (valid ? qi : 0));
+    const float* qp = qkv + row * ld + head * D;
+    const float* op = o + row * H + head * D;
+    const float* dp = dout + row * H + head * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { q[d] = qp[d] * sl2; dO[d] = dp[d]; dsum += dp[d] * op[d]; dq[d] = 0.f; }
+    lse = lse2[row * nh + head];
+    if (valid) Dq[row * nh + head] = dsum;
+  }
+  const int kend = min(L, q0 + BQ);
+  for (int kt = 0; kt < kend; kt += BT) {
+    __syncthreads();
+    for (int idx = lane; idx < BT * D / 4; idx += 64) {
+      const int key = idx >> 4, d4 = (idx & 15) * 4;
+      const float* base = qkv + (size_t)(t0 + min(kt + key, L - 1)) * ld + head * D + d4;
+      *reinterpret_cast<float4*>(s_k + key * D + d4) = *reinterpret_cast<const float4*>(base + H);
+      *reinterpret_cast<float4*>(s_v + key * D + d4) = *reinterpret_cast<const float4*>(base + 2 * H);
+    }
+    __syncthreads();
+    for (int j = 0; j < BT; ++j) {
+      const int kj = kt + j;
+      if (kj >= kend) break;                               // uniform
+      const float* kr = s_k + j * D;
+      const float* vr = s_v + j * D;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { s = fmaf(q[d], kr[d], s); dp = fmaf(dO[d], vr[d], dp); }
+      const float p = (valid && kj <= qi) ? exp2f(s - lse) : 0.f;
+      const float ds = p * (dp - dsum);
+#pragma unroll
+      for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
+    }
+  }
+  if (!valid) return;
+  float* out = dqkv + (size_t)(t0 + qi) * ld + head * D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) out[d] = dq[d] * scale;
+}
+
+// one lane per key: dV (pass 0) and dK (pass 1); queries streamed through LDS
+__global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          const float* __restrict__ lse2, const float* __restrict__ Dq,
+                                                          const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc,
+                                                          int n_req, int H, float scale, float* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) float s_q[BT * D];
+  __shared__ __attribute__((aligned(16))) float s_do[BT * D];
+  __shared__ float s_lse[BT], s_dq[BT];
+  const int b = blockIdx.x;
+  if (b >= blk_start[n_req]) return;
+  const int head = blockIdx.y, lane = threadIdx.x, nh = H / D;
+  const int4 desc = blk_desc[b];
+  const int k0 = desc.y, t0 = desc.z, L = desc.w;
+  const int ki = k0 + lane;
+  const bool valid = ki < L;
+  const size_t ld = (size_t)3 * H;
+  const float sl2 = scale * 1.4426950408889634f;
+  float kk[D], vv[D], acc[D];
+  {
+    const float* kp = qkv + (size_t)(t0 + (valid ? ki : 0)) * ld + H + head * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { kk[d] = kp[d]; vv[d] = kp[H + d]; }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    for (int qt = k0; qt < L; qt += BT) {                  // queries >= the first key of this block
+      __syncthreads();
+      for (int idx = lane; idx < BT * D / 4; idx += 64) {
+        const int qq = idx >> 4, d4 = (idx & 15) * 4;
+        const size_t row = (size_t)(t0 + min(qt + qq, L - 1));
+        float4 qv = *reinterpret_cast<const float4*>(qkv + row * ld + head * D + d4);
+        qv.x *= sl2; qv.y *= sl2; qv.z *= sl2; qv.w *= sl2;
+        *reinterpret_cast<float4*>(s_q + qq * D + d4) = qv;
+        *reinterpret_cast<float4*>(s_do + qq * D + d4) = *reinterpret_cast<const float4*>(dout + row * H + head * D + d4);
+      }
+      if (lane < BT) {
+        const size_t row = (size_t)(t0 + min(qt + lane, L - 1));
+        s_lse[lane] = lse2[row * nh + head];
+        s_dq[lane] = Dq[row * nh + head];
+      }
+      __syncthreads();
+      for (int j = 0; j < BT; ++j) {
+        const int qj = qt + j;
+        if (qj >= L) break;                                // uniform
+        const float* qr = s_q + j * D;
+        const float* dr = s_do + j * D;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s = fmaf(qr[d], kk[d], s); dp = fmaf(dr[d], vv[d], dp); }
+        const float p = (valid && qj >= ki) ? exp2f(s - s_lse[j]) : 0.f;
+        if (pass == 0) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) acc[d] = fmaf(p, dr[d], acc[d]);
+        } else {
+          const float ds = p * (dp - s_dq[j]);
+#pragma unroll
+          for (int d = 0; d < D; ++d) acc[d] = fmaf(ds, qr[d], acc[d]);
+        }
+      }
+    }
+    if (valid) {
+      // pass 0 -> dV; pass 1 -> dK = scale sum dS q = sum dS (q scale log2e) / log2e
+      float* out = dqkv + (size_t)(t0 + ki) * ld + (pass == 0 ? 2 * H : H) + head * D;
+      const float f = pass == 0 ? 1.f : 0.6931471805599453f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) out[d] = acc[d] * f;
+    }
+  }
+}
+
+inline size_t up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace
+}  // namespace ltr
+
+using namespace ltr;
+
+// ----------------------------------------------------------------------------------------------------------------
+// trainer object
+// ----------------------------------------------------------------------------------------------------------------
+struct ltr_trainer {
+  ltr_model_desc d;
+  ltr_train_config cfg;
+  int device = 0;
+  int64_t step = 0;
+  size_t total = 0;
+  std::vector<size_t> off, cnt;        // per weight index (ltr_create's index space)
+  float *P = nullptr, *G = nullptr, *M1 = nullptr, *V1 = nullptr, *wT = nullptr;
+  size_t wT_elems = 0;
+  ~ltr_trainer() {
+    for (float* p : {P, G, M1, V1, wT}) if (p) (void)hipFree(p);
+  }
+  float* p(int idx) const { return P + off[idx]; }
+  float* g(int idx) const { return G + off[idx]; }
+  int li(int layer, int i) const { return LTR_WT_GLOBAL_COUNT + layer * LTR_WL_COUNT + i; }
+};
+
+namespace {
+
+struct DevGuard {
+  int prev = -1; bool sw = false;
+  explicit DevGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) sw = hipSetDevice(dev) == hipSuccess; }
+  ~DevGuard() { if (sw) (void)hipSetDevice(prev); }
+};
+
+size_t weight_count(const ltr_model_desc& d, int idx) {
+  const size_t H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim;
+  const bool proj = De != H;
+  if (idx < LTR_WT_GLOBAL_COUNT) {
+    switch (idx) {
+      case LTR_WT_EMBED_TOKENS: return (size_t)d.vocab_size * De;
+      case LTR_WT_EMBED_POS: return (size_t)d.pos_rows * H;
+      case LTR_WT_PROJECT_IN: return proj ? H * De : 0;
+      case LTR_WT_PROJECT_OUT: return proj ? De * H : 0;
+      case LTR_WT_FINAL_LN_W: case LTR_WT_FINAL_LN_B: return d.pre_ln ? H : 0;
+      case LTR_WT_SCORE: return (size_t)d.num_labels * De;
+    }
+    return 0;
+  }
+  switch ((idx - LTR_WT_GLOBAL_COUNT) % LTR_WL_COUNT) {
+    case LTR_WL_QKV_W: return 3 * H * H;
+    case LTR_WL_QKV_B: return 3 * H;
+    case LTR_WL_OUT_W: return H * H;
+    case LTR_WL_FC1_W: case LTR_WL_FC2_W: return F * H;
+    case LTR_WL_FC1_B: return F;
+    default: return H;     // out / fc2 bias, LayerNorm terms
+  }
+}
+
+// workspace carve-up of one step
+struct TrainWs {
+  struct Layer { float *x0, *n1, *qkv, *ao, *lse, *mid, *n2, *f, *ao_raw, *mlp_raw; };
+  std::vector<Layer> L;
+  float *tok, *hfin, *hl, *z, *y, *logits, *dlogits, *row_loss, *dy, *dz, *dhl;
+  float *dh, *dbig, *dsmall, *dsmall2, *xhd, *t1, *t2, *partial, *Dq;
+  int32_t* blk;
+  size_t bytes;
+};
+
+TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, bool dropout) {
+  const size_t H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, nh = d.num_heads, nl = d.num_labels;
+  const size_t Tp = (T + 15) / 16 * 16, Np = (N + 15) / 16 * 16;
+  const size_t big = std::max<size_t>(3 * H, F);
+  char* p = (char*)base;
+  size_t o = 0;
+  auto take = [&](size_t n_floats) { size_t q = o; o += up(n_floats * 4); return base ? (float*)(p + q) : (float*)nullptr; };
+  TrainWs w;
+  w.L.resize(d.num_layers);
+  for (auto& l : w.L) {
+    l.x0 = take(T * H); l.n1 = take(T * H); l.qkv = take(T * 3 * H); l.ao = take(T * H); l.lse = take(T * nh);
+    l.mid = take(T * H); l.n2 = take(T * H); l.f = take(T * F);
+    l.ao_raw = dropout ? take(T * H) : nullptr; l.mlp_raw = dropout ? take(T * H) : nullptr;
+  }
+  w.tok = take(T * De); w.hfin = take(T * H);
+  w.hl = take(Np * H); w.z = take(Np * H); w.y = take(Np * De); w.logits = take(N * nl); w.dlogits = take(N * nl);
+  w.row_loss = take(N + 8); w.dy = take(Np * De); w.dz = take(Np * H); w.dhl = take(Np * H);
+  w.dh = take(T * H); w.dbig = take(T * big); w.dsmall = take(T * H); w.dsmall2 = take(T * H); w.xhd = take(T * H);
+  w.t1 = take(big * Tp); w.t2 = take(big * Tp);
+  w.partial = take(((size_t)(T + 255) / 256 + 1) * big);
+  w.Dq = take(T * nh);
+  w.blk = (int32_t*)take((N + 4) + (T / 64 + N + 1) * 4);
+  w.bytes = o;
+  return w;
+}
+
+struct Ctx {
+  ltr_trainer* t;
+  hipStream_t s;
+  TrainWs ws;
+  int T, N;
+};
+
+int gemm_nt(const float* A, const float* B, const float* bias, const float* resid, float* out, int M, int N, int K, int relu,
+            hipStream_t s) {
+  GemmArgs g{};
+  g.a = AOp{(void*)A, nullptr}; g.w = B; g.bias = bias; g.resid = resid; g.out_f32 = out; g.M = M; g.N = N; g.K = K; g.relu = relu;
+  return launch_gemm(LTR_W_F32, g, s);
+}
+int transpose_pad(const float* in, int R, int C, int Rp, float* out, hipStream_t s) {
+  dim3 grid((C + 31) / 32, (Rp + 31) / 32);
+  transpose_pad_kernel<<<grid, 256, 0, s>>>(in, R, C, Rp, out);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+// dX[M, K] = (resid) + dY[M, N] W[N, K]
+int gemm_nn(Ctx& c, const float* dY, const float* W, const float* resid, float* dX, int M, int N, int K) {
+  int rc = transpose_pad(W, N, K, N, c.t->wT, c.s);          // W^T [K, N]
+  if (rc) return rc;
+  return gemm_nt(dY, c.t->wT, nullptr, resid, dX, M, K, N, 0, c.s);
+}
+// dW[N, K] = dY[M, N]^T X[M, K]
+int gemm_tn(Ctx& c, const float* dY, const float* X, float* dW, int M, int N, int K) {
+  const int Mp = (M + 15) / 16 * 16;
+  int rc = transpose_pad(dY, M, N, Mp, c.ws.t1, c.s);        // [N, Mp]
+  if (rc) return rc;
+  if ((rc = transpose_pad(X, M, K, Mp, c.ws.t2, c.s))) return rc;   // [K, Mp]
+  return gemm_nt(c.ws.t1, c.ws.t2, nullptr, nullptr, dW, N, K, Mp, 0, c.s);
+}
+int colsum(Ctx& c, const float* x, const float* y, int M, int N, float* out) {
+  const int nb = (M + 255) / 256;
+  dim3 grid((N + 255) / 256, nb);
+  colsum_partial_kernel<<<grid, 256, 0, c.s>>>(x, y, M, N, c.ws.partial);
+  LTR_LAUNCH_CHECK();
+  colsum_final_kernel<<<(N + 255) / 256, 256, 0, c.s>>>(c.ws.partial, nb, N, out);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+// LayerNorm backward of y = LN(x): dx_out = base + dLN; accumulates dgamma / dbeta into dg / db (plain stores: once per step)
+int ln_bwd(Ctx& c, const float* x, const float* gamma, const float* dy, const float* base, int M, int H, float* dx_out,
+           float* dg, float* db) {
+  ln_bwd_kernel<<<(M + 3) / 4, 256, 0, c.s>>>(x, gamma, dy, base, M, H, dx_out, c.ws.xhd);
+  LTR_LAUNCH_CHECK();
+  int rc = colsum(c, c.ws.xhd, nullptr, M, H, dg);
+  if (rc) return rc;
+  return colsum(c, dy, nullptr, M, H, db);
+}
+uint64_t drop_seed(const ltr_trainer* t, int layer, int site) {
+  return (t->cfg.seed * 0x100000001B3ull) ^ ((uint64_t)t->step << 20) ^ ((uint64_t)layer << 4) ^ (uint64_t)site;
+}
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+int forward(Ctx& c, const int64_t* ids, const int32_t* cu) {
+  ltr_trainer* t = c.t;
+  const ltr_model_desc& d = t->d;
+  const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, T = c.T, N = c.N, nl = d.num_labels;
+  const bool proj = De != H, drop = t->cfg.dropout > 0.f;
+  hipStream_t s = c.s;
+  float* h0 = d.num_layers ? c.ws.L[0].x0 : c.ws.hfin;
+  RC(launch_embed_gather(LTR_W_F32, ids, cu, N, T, 0, t->p(LTR_WT_EMBED_TOKENS), De, d.vocab_size, t->p(LTR_WT_EMBED_POS), H,
+                         d.pos_rows, h0, AOp{c.ws.tok, nullptr}, nullptr, s));
+  if (proj) RC(gemm_nt(c.ws.tok, t->p(LTR_WT_PROJECT_IN), nullptr, h0, h0, T, H, De, 0, s));
+  for (int l = 0; l < d.num_layers; ++l) {
+    auto& L = c.ws.L[l];
+    float* out = l + 1 < d.num_layers ? c.ws.L[l + 1].x0 : c.ws.hfin;
+    const float* qkv_in = L.x0;
+    if (d.pre_ln) {
+      RC(launch_layernorm(LTR_W_F32, L.x0, t->p(t->li(l, LTR_WL_LN1_W)), t->p(t->li(l, LTR_WL_LN1_B)), T, H, L.n1, AOp{nullptr, nullptr}, s));
+      qkv_in = L.n1;
+    }
+    RC(gemm_nt(qkv_in, t->p(t->li(l, LTR_WL_QKV_W)), t->p(t->li(l, LTR_WL_QKV_B)), nullptr, L.qkv, T, 3 * H, H, 0, s));
+    RC(launch_attention(LTR_W_F32, AOp{L.qkv, nullptr}, cu, N, T, H, d.num_heads, c.ws.blk, AOp{L.ao, nullptr}, l == 0, s, L.lse));
+    // s1 = x0 + dropout(out_proj(ao))
+    float* s1 = d.pre_ln ? L.mid : L.n1;
+    if (drop) {
+      RC(gemm_nt(L.ao, t->p(t->li(l, LTR_WL_OUT_W)), t->p(t->li(l, LTR_WL_OUT_B)), nullptr, L.ao_raw, T, H, H, 0, s));
+      dropout_add_kernel<<<1024, 256, 0, s>>>(L.ao_raw, L.x0, s1, (size_t)T * H, drop_seed(t, l, 0), t->cfg.dropout);
+      LTR_LAUNCH_CHECK();
+    } else {
+      RC(gemm_nt(L.ao, t->p(t->li(l, LTR_WL_OUT_W)), t->p(t->li(l, LTR_WL_OUT_B)), L.x0, s1, T, H, H, 0, s));
+    }
+    const float* mlp_in;
+    if (d.pre_ln) {
+      RC(launch_layernorm(LTR_W_F32, L.mid, t->p(t->li(l, LTR_WL_LN2_W)), t->p(t->li(l, LTR_WL_LN2_B)), T, H, L.n2, AOp{nullptr, nullptr}, s));
+      mlp_in = L.n2;
+    } else {
+      RC(launch_layernorm(LTR_W_F32, L.n1, t->p(t->li(l, LTR_WL_LN1_W)), t->p(t->li(l, LTR_WL_LN1_B)), T, H, L.mid, AOp{nullptr, nullptr}, s));
+      mlp_in = L.mid;
+    }
+    RC(gemm_nt(mlp_in, t->p(t->li(l, LTR_WL_FC1_W)), t->p(t->li(l, LTR_WL_FC1_B)), nullptr, L.f, T, F, H, 1, s));
+    float* s2 = d.pre_ln ? out : L.n2;
+    if (drop) {
+      RC(gemm_nt(L.f, t->p(t->li(l, LTR_WL_FC2_W)), t->p(t->li(l, LTR_WL_FC2_B)), nullptr, L.mlp_raw, T, H, F, 0, s));
+      dropout_add_kernel<<<1024, 256, 0, s>>>(L.mlp_raw, L.mid, s2, (size_t)T * H, drop_seed(t, l, 1), t->cfg.dropout);
+      LTR_LAUNCH_CHECK();
+    } else {
+      RC(gemm_nt(L.f, t->p(t->li(l, LTR_WL_FC2_W)), t->p(t->li(l, LTR_WL_FC2_B)), L.mid, s2, T, H, F, 0, s));
+    }
+    if (!d.pre_ln)
+      RC(launch_layernorm(LTR_W_F32, L.n2, t->p(t->li(l, LTR_WL_LN2_W)), t->p(t->li(l, LTR_WL_LN2_B)), T, H, out, AOp{nullptr, nullptr}, s));
+  }
+  // head: last-token rows -> (final LN) -> (project_out) -> score.weight
+  const int Np = (N + 15) / 16 * 16;
+  LTR_HIP_CHECK(hipMemsetAsync(c.ws.hl, 0, (size_t)Np * H * 4, s));
+  gather_rows_kernel<<<N, 256, 0, s>>>(c.ws.hfin, cu, N, H, c.ws.hl);
+  LTR_LAUNCH_CHECK();
+  const float* z = c.ws.hl;
+  if (d.pre_ln) {
+    RC(launch_layernorm(LTR_W_F32, c.ws.hl, t->p(LTR_WT_FINAL_LN_W), t->p(LTR_WT_FINAL_LN_B), N, H, c.ws.z, AOp{nullptr, nullptr}, s));
+    z = c.ws.z;
+  }
+  const float* y = z;
+  if (proj) { RC(gemm_nt(z, t->p(LTR_WT_PROJECT_OUT), nullptr, nullptr, c.ws.y, N, De, H, 0, s)); y = c.ws.y; }
+  head_fwd_kernel<<<(unsigned)(((size_t)N * nl + 3) / 4), 256, 0, s>>>(y, t->p(LTR_WT_SCORE), N, De, nl, c.ws.logits);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
+  ltr_trainer* t = c.t;
+  const ltr_model_desc& d = t->d;
+  const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, T = c.T, N = c.N, nl = d.num_labels;
+  const bool proj = De != H, drop = t->cfg.dropout > 0.f;
+  hipStream_t s = c.s;
+  const float scale = 0.125f;
+  // head
+  const float* z = d.pre_ln ? c.ws.z : c.ws.hl;
+  const float* y = proj ? c.ws.y : z;
+  head_bwd_dw_kernel<<<(unsigned)(((size_t)nl * De + 255) / 256), 256, 0, s>>>(c.ws.dlogits, y, N, De, nl, t->g(LTR_WT_SCORE));
+  LTR_LAUNCH_CHECK();
+  const int Np = (N + 15) / 16 * 16;
+  LTR_HIP_CHECK(hipMemsetAsync(c.ws.dy, 0, (size_t)Np * De * 4, s));
+  head_bwd_dy_kernel<<<(unsigned)(((size_t)N * De + 255) / 256), 256, 0, s>>>(c.ws.dlogits, t->p(LTR_WT_SCORE), N, De, nl, c.ws.dy);
+  LTR_LAUNCH_CHECK();
+  const float* dz = c.ws.dy;
+  if (proj) {
+    RC(gemm_tn(c, c.ws.dy, z, t->g(LTR_WT_PROJECT_OUT), N, De, H));
+    RC(gemm_nn(c, c.ws.dy, t->p(LTR_WT_PROJECT_OUT), nullptr, c.ws.dz, N, De, H));
+    dz = c.ws.dz;
+  }
+  const float* dhl = dz;
+  if (d.pre_ln) {
+    RC(ln_bwd(c, c.ws.hl, t->p(LTR_WT_FINAL_LN_W), dz, nullptr, N, H, c.ws.dhl, t->g(LTR_WT_FINAL_LN_W), t->g(LTR_WT_FINAL_LN_B)));
+    dhl = c.ws.dhl;
+  }
+  LTR_HIP_CHECK(hipMemsetAsync(c.ws.dh, 0, (size_t)T * H * 4, s));
+  scatter_rows_kernel<<<N, 256, 0, s>>>(dhl, cu, N, H, c.ws.dh);
+  LTR_LAUNCH_CHECK();
+  float* dh = c.ws.dh;
+  int4* blk_desc = reinterpret_cast<int4*>(c.ws.blk + ((N + 1 + 3) & ~3));
+  for (int l = d.num_layers - 1; l >= 0; --l) {
+    auto& L = c.ws.L[l];
+    auto P = [&](int i) { return t->p(t->li(l, i)); };
+    auto G = [&](int i) { return t->g(t->li(l, i)); };
+    const float* mlp_in = d.pre_ln ? L.n2 : L.mid;
+    const float* qkv_in = d.pre_ln ? L.n1 : L.x0;
+    // ---- MLP half.  ds2 = gradient w.r.t. s2 = mid + dropout(mlp)
+    float* ds2 = dh;
+    if (!d.pre_ln) {       // out = LN2(s2)
+      RC(ln_bwd(c, L.n2, P(LTR_WL_LN2_W), dh, nullptr, T, H, c.ws.dsmall, G(LTR_WL_LN2_W), G(LTR_WL_LN2_B)));
+      ds2 = c.ws.dsmall;
+    }
+    const float* dmlp = ds2;
+    if (drop) {
+      dropout_add_kernel<<<1024, 256, 0, s>>>(ds2, nullptr, c.ws.dsmall2, (size_t)T * H, drop_seed(t, l, 1), t->cfg.dropout);
+      LTR_LAUNCH_CHECK();
+      dmlp = c.ws.dsmall2;
+    }
+    RC(gemm_tn(c, dmlp, L.f, G(LTR_WL_FC2_W), T, H, F));
+    RC(colsum(c, dmlp, nullptr, T, H, G(LTR_WL_FC2_B)));
+    RC(gemm_nn(c, dmlp, P(LTR_WL_FC2_W), nullptr, c.ws.dbig, T, H, F));            // df [T, F]
+    relu_bwd_kernel<<<1024, 256, 0, s>>>(c.ws.dbig, L.f, (size_t)T * F);
+    LTR_LAUNCH_CHECK();
+    RC(gemm_tn(c, c.ws.dbig, mlp_in, G(LTR_WL_FC1_W), T, F, H));
+    RC(colsum(c, c.ws.dbig, nullptr, T, F, G(LTR_WL_FC1_B)));
+    // ---- dmid = ds2 + d(mlp_in -> mid)
+    float* dmid;
+    if (d.pre_ln) {        // mlp_in = LN2(mid): dmid = ds2 + LN2_bwd(da2)
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_FC1_W), nullptr, c.ws.dsmall, T, F, H));   // da2 (pre-LN has not used dsmall so far)
+      RC(ln_bwd(c, L.mid, P(LTR_WL_LN2_W), c.ws.dsmall, ds2, T, H, dh, G(LTR_WL_LN2_W), G(LTR_WL_LN2_B)));
+      dmid = dh;
+    } else {               // mlp_in = mid
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_FC1_W), ds2, dh, T, F, H));
+      dmid = dh;
+    }
+    // ---- attention half.  ds1 = gradient w.r.t. s1 = x0 + dropout(out_proj(ao))
+    float* ds1 = dmid;
+    if (!d.pre_ln) {       // mid = LN1(s1)
+      RC(ln_bwd(c, L.n1, P(LTR_WL_LN1_W), dmid, nullptr, T, H, c.ws.dsmall, G(LTR_WL_LN1_W), G(LTR_WL_LN1_B)));
+      ds1 = c.ws.dsmall;
+    }
+    const float* dproj = ds1;
+    if (drop) {
+      dropout_add_kernel<<<1024, 256, 0, s>>>(ds1, nullptr, c.ws.dsmall2, (size_t)T * H, drop_seed(t, l, 0), t->cfg.dropout);
+      LTR_LAUNCH_CHECK();
+      dproj = c.ws.dsmall2;
+    }
+    RC(gemm_tn(c, dproj, L.ao, G(LTR_WL_OUT_W), T, H, H));
+    RC(colsum(c, dproj, nullptr, T, H, G(LTR_WL_OUT_B)));
+    float* dao = c.ws.xhd;                                                           // free between LN backward calls
+    RC(gemm_nn(c, dproj, P(LTR_WL_OUT_W), nullptr, dao, T, H, H));
+    {
+      dim3 grid(T / BQ + N, d.num_heads);
+      attn_bwd_dq_kernel<<<grid, 64, 0, s>>>(L.qkv, L.ao, dao, L.lse, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig, c.ws.Dq);
+      LTR_LAUNCH_CHECK();
+      attn_bwd_dkv_kernel<<<grid, 64, 0, s>>>(L.qkv, dao, L.lse, c.ws.Dq, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig);
+      LTR_LAUNCH_CHECK();
+    }
+    RC(gemm_tn(c, c.ws.dbig, qkv_in, G(LTR_WL_QKV_W), T, 3 * H, H));
+    RC(colsum(c, c.ws.dbig, nullptr, T, 3 * H, G(LTR_WL_QKV_B)));
+    if (d.pre_ln) {        // qkv_in = LN1(x0): dx0 = ds1 + LN1_bwd
+      float* da1 = c.ws.dsmall2;
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_QKV_W), nullptr, da1, T, 3 * H, H));
+      RC(ln_bwd(c, L.x0, P(LTR_WL_LN1_W), da1, ds1, T, H, dh, G(LTR_WL_LN1_W), G(LTR_WL_LN1_B)));
+    } else {               // qkv_in = x0
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_QKV_W), ds1, dh, T, 3 * H, H));
+    }
+  }
+  // embedding: h0 = project_in(tok) + pos
+  const float* dtok = dh;
+  if (proj) {
+    RC(gemm_tn(c, dh, c.ws.tok, t->g(LTR_WT_PROJECT_IN), T, H, De));
+    RC(gemm_nn(c, dh, t->p(LTR_WT_PROJECT_IN), nullptr, c.ws.dsmall, T, H, De));
+    dtok = c.ws.dsmall;
+  }
+  embed_bwd_kernel<<<T, 256, 0, s>>>(ids, cu, N, T, dh, dtok, H, De, d.vocab_size, d.pos_rows, t->g(LTR_WT_EMBED_POS),
+                                     t->g(LTR_WT_EMBED_TOKENS));
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ltr_train_create(const ltr_model_desc* desc, const void* const* weights, int32_t n_weights,
+                     const ltr_train_config* cfg, void* stream, ltr_train_handle* out) {
+  if (!desc || !weights || !cfg || !out) { set_error("ltr_train_create: NULL argument"); return LTR_E_INVAL; }
+  const ltr_model_desc& d = *desc;
+  if (d.hidden_size <= 0 || d.hidden_size != d.num_heads * 64 || d.ffn_dim % 64 || d.word_embed_proj_dim % 64 ||
+      d.num_labels < 1 || d.num_layers < 0 || d.pos_rows < 3 || d.vocab_size < 1) {
+    set_error("ltr_train_create: head size must be 64; F and De multiples of 64");
+    return LTR_E_INVAL;
+  }
+  if (cfg->loss != LTR_LOSS_LISTMLE && cfg->loss != LTR_LOSS_MSE && cfg->loss != LTR_LOSS_CROSSENTROPY) {
+    set_error("ltr_train_create: unknown loss %d", cfg->loss); return LTR_E_INVAL;
+  }
+  if (cfg->loss != LTR_LOSS_CROSSENTROPY && d.num_labels != 1) {
+    set_error("ltr_train_create: listMLE / mse train a 1-label (rank) head (prefill_predictor.py:35-36)"); return LTR_E_INVAL;
+  }
+  if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) { set_error("ltr_train_create: dropout must be in [0, 1)"); return LTR_E_INVAL; }
+  const int want = LTR_WT_GLOBAL_COUNT + d.num_layers * LTR_WL_COUNT;
+  if (n_weights != want) { set_error("ltr_train_create: %d weight pointers, expected %d", n_weights, want); return LTR_E_INVAL; }
+  ltr_trainer* t = new (std::nothrow) ltr_trainer();
+  if (!t) { set_error("ltr_train_create: out of host memory"); return LTR_E_NOMEM; }
+  t->d = d; t->cfg = *cfg;
+  t->off.resize(want); t->cnt.resize(want);
+  size_t total = 0, wmax = 0;
+  for (int i = 0; i < want; ++i) {
+    t->cnt[i] = weight_count(d, i);
+    t->off[i] = total;
+    total += (t->cnt[i] + 63) / 64 * 64;
+    if (t->cnt[i] && !weights[i]) { delete t; set_error("ltr_train_create: weight pointer %d is NULL", i); return LTR_E_INVAL; }
+    const int li = i < LTR_WT_GLOBAL_COUNT ? -1 : (i - LTR_WT_GLOBAL_COUNT) % LTR_WL_COUNT;
+    const bool mat = i == LTR_WT_PROJECT_IN || i == LTR_WT_PROJECT_OUT || li == LTR_WL_QKV_W || li == LTR_WL_OUT_W ||
+                     li == LTR_WL_FC1_W || li == LTR_WL_FC2_W;
+    if (mat) wmax = std::max(wmax, t->cnt[i]);
+  }
+  t->total = total;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, weights[LTR_WT_EMBED_TOKENS]) != hipSuccess) {
+      (void)hipGetLastError(); delete t; set_error("ltr_train_create: weight pointers must be device memory"); return LTR_E_INVAL;
+    }
+    t->device = attr.device;
+  }
+  DevGuard guard(t->device);
+  hipStream_t s = (hipStream_t)stream;
+  t->wT_elems = wmax;
+  if (hipMalloc((void**)&t->P, total * 4) != hipSuccess || hipMalloc((void**)&t->G, total * 4) != hipSuccess ||
+      hipMalloc((void**)&t->M1, total * 4) != hipSuccess || hipMalloc((void**)&t->V1, total * 4) != hipSuccess ||
+      hipMalloc((void**)&t->wT, std::max<size_t>(wmax, 64) * 4) != hipSuccess) {
+    delete t; set_error("ltr_train_create: cannot allocate %zu parameters x 4 buffers", total); return LTR_E_NOMEM;
+  }
+  if (hipMemsetAsync(t->P, 0, total * 4, s) != hipSuccess || hipMemsetAsync(t->M1, 0, total * 4, s) != hipSuccess ||
+      hipMemsetAsync(t->V1, 0, total * 4, s) != hipSuccess) { delete t; set_error("ltr_train_create: memset failed"); return LTR_E_HIP; }
+  for (int i = 0; i < want; ++i)
+    if (t->cnt[i] && hipMemcpyAsync(t->P + t->off[i], weights[i], t->cnt[i] * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      delete t; set_error("ltr_train_create: copying weight %d failed", i); return LTR_E_HIP;
+    }
+  if (hipStreamSynchronize(s) != hipSuccess) { delete t; set_error("ltr_train_create: copy failed"); return LTR_E_HIP; }
+  *out = t;
+  return LTR_OK;
+}
+
+int ltr_train_destroy(ltr_train_handle h) {
+  if (h) { DevGuard guard(h->device); delete h; }
+  return LTR_OK;
+}
+
+size_t ltr_train_workspace_bytes(ltr_train_handle h, int64_t N, int64_t T) {
+  if (!h || N <= 0 || T <= 0) return 0;
+  return carve_train(h->d, T, N, nullptr, h->cfg.dropout > 0.f).bytes;
+}
+
+int ltr_train_read(ltr_train_handle h, int32_t index, int32_t what, float* dst, size_t capacity, size_t* count_out,
+                   void* stream) {
+  if (!h || index < 0 || index >= (int)h->off.size() || !count_out || (what != 0 && what != 1)) {
+    set_error("ltr_train_read: bad argument"); return LTR_E_INVAL;
+  }
+  *count_out = h->cnt[index];
+  if (!dst || h->cnt[index] == 0) return LTR_OK;           // size query / absent tensor
+  if (capacity < h->cnt[index]) { set_error("ltr_train_read: %zu floats do not fit %zu", h->cnt[index], capacity); return LTR_E_NOMEM; }
+  DevGuard guard(h->device);
+  const float* src = (what == 0 ? h->P : h->G) + h->off[index];
+  LTR_HIP_CHECK(hipMemcpyAsync(dst, src, h->cnt[index] * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return LTR_OK;
+}
+
+int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, const int32_t* cu_seqlens_host,
+                   int32_t N, int32_t T, const float* labels, const int32_t* shuffle, int32_t apply_update, float* loss_out,
+                   float* logits_out, void* workspace, size_t ws_bytes, void* stream) {
+  if (!h || !token_ids || !cu_seqlens || !cu_seqlens_host || !labels || !loss_out || !workspace || N <= 0 || T <= 0) {
+    set_error("ltr_train_step: bad argument"); return LTR_E_INVAL;
+  }
+  const ltr_model_desc& d = h->d;
+  if (cu_seqlens_host[0] != 0 || cu_seqlens_host[N] != T) { set_error("ltr_train_step: cu_seqlens does not span T"); return LTR_E_INVAL; }
+  for (int r = 0; r < N; ++r) {
+    const int L = cu_seqlens_host[r + 1] - cu_seqlens_host[r];
+    if (L <= 0 || L > d.pos_rows - 2) { set_error("ltr_train_step: request %d has %d tokens (1..%d allowed)", r, L, d.pos_rows - 2); return LTR_E_INVAL; }
+  }
+  if (h->cfg.loss == LTR_LOSS_LISTMLE && (!shuffle || N > 4096)) { set_error("ltr_train_step: listMLE needs the shuffle permutation and a slate of at most 4096"); return LTR_E_INVAL; }
+  DevGuard guard(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{h, s, carve_train(d, T, N, workspace, h->cfg.dropout > 0.f), T, N};
+  if (c.ws.bytes > ws_bytes) { set_error("ltr_train_step: workspace too small (%zu < %zu)", ws_bytes, c.ws.bytes); return LTR_E_NOMEM; }
+  int rc = forward(c, token_ids, cu_seqlens);
+  if (rc) return rc;
+  const int nl = d.num_labels;
+  if (logits_out) LTR_HIP_CHECK(hipMemcpyAsync(logits_out, c.ws.logits, (size_t)N * nl * 4, hipMemcpyDeviceToDevice, s));
+  if (h->cfg.loss == LTR_LOSS_LISTMLE) {       // trainer.py:157: loss_func(outputs.view(1, -1), labels) - the batch is one slate
+    rc = ltr_listmle(c.ws.logits, labels, shuffle, 1, N, h->cfg.listmle_eps, h->cfg.pad_value, loss_out, c.ws.row_loss,
+                     c.ws.dlogits, stream);
+    if (rc) return rc;
+  } else if (h->cfg.loss == LTR_LOSS_MSE) {
+    mse_kernel<<<1, 256, 0, s>>>(c.ws.logits, labels, N, loss_out, c.ws.dlogits);
+    LTR_LAUNCH_CHECK();
+  } else {
+    ce_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(c.ws.logits, labels, N, nl, c.ws.row_loss, c.ws.dlogits);
+    LTR_LAUNCH_CHECK();
+    mean_kernel<<<1, 64, 0, s>>>(c.ws.row_loss, N, loss_out);
+    LTR_LAUNCH_CHECK();
+  }
+  LTR_HIP_CHECK(hipMemsetAsync(h->G, 0, h->total * 4, s));        // optimizer.zero_grad() (trainer.py:165)
+  if ((rc = backward(c, token_ids, cu_seqlens))) return rc;
+  h->step += 1;
+  if (apply_update) {                                                // optimizer.step() (trainer.py:163)
+    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
+    const float bc1 = (float)(1.0 - std::pow(b1, (double)h->step)), bc2 = (float)(1.0 - std::pow(b2, (double)h->step));
+    adam_kernel<<<2048, 256, 0, s>>>(h->P, h->G, h->M1, h->V1, h->total, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps,
+                                     h->cfg.weight_decay, bc1, bc2);
+    LTR_LAUNCH_CHECK();
+  }
+  return LTR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""Fine-tuning of the predictor on the device (``ltr_train_step`` of libltr_hip.so) - the host-side mirror of
+the reference's training loop, ``train/trainer.py:85-216``:
+
+    predictor = prefill_predictor_model(pred_model=..., num_labels=..., mtype=...)        # :99-101 fp32 master weights
+    optimizer = torch.optim.Adam(predictor.model.parameters(), lr=args.lr, weight_decay=args.wc)     # :122
+    for prompt, labels, origin_len in train_dataloader:                                            # :137
+        outputs = predictor(input_ids, attention_mask)                                             # :146
+        loss = loss_func(outputs.view(1, -1), labels)   # listMLE / mse; crossentropy over classes   # :150-157
+        loss.backward(); optimizer.step(); optimizer.zero_grad()                                    # :161-165
+    predictor.model.half().save_pretrained(finetuned_model_output_path)                              # :213-216
+
+:class:`HipPredictorTrainer` keeps parameters, gradients and Adam moments in HBM (f32); ``step`` runs forward, loss,
+backward and the Adam update as HIP kernels; ``save_pretrained`` writes the HF-format fp16 checkpoint + the
+``usage_config.json`` the serving side loads (``MI355XRanker.from_predictor_config``).  Tokenisation is the caller's
+(no tokenizer files offline): a slate is a list of token-id lists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config_predictor import PrefillModelConfig, PrefillPredictorConfig
+from .opt_spec import OPTSpec, save_hf_checkpoint
+
+
+def len2label(length: int, label_max_length: int = 8192, label_group_size: int = 1) -> int:
+    """``RankingDataset.__len2label__`` (trainer.py:52-54): shorter generations get LARGER labels."""
+    return label_max_length // label_group_size - min(label_max_length, length) // label_group_size
+
+
+class HipPredictorTrainer:
+    def __init__(self, spec: OPTSpec, ckpt: Dict[str, np.ndarray], device: str = "cuda:0", lr: float = 2e-5,
+                 weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, loss: str = "listMLE",
+                 dropout: float = 0.0, seed: int = 42):
+        """Defaults are the reference's: ``--lr 2e-5 --wc 0.01`` (trainer.py:28-29), Adam's betas / eps, seed 42 (:86).
+        ``dropout``: HF OPT trains with 0.1; 0 keeps the step reproducible against other implementations."""
+        if not torch.cuda.is_available():
+            raise _lib.LtrError("HipPredictorTrainer needs a ROCm GPU (no CPU fallback on the product path)")
+        if loss not in _lib.LOSSES:
+            raise ValueError(f"loss {loss!r}: one of {sorted(_lib.LOSSES)} (trainer.py:125-132; neuralNDCG is not built)")
+        self.lib = _lib.load()
+        self.spec, self.loss = spec, loss
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        f32 = lambda name: torch.from_numpy(np.ascontiguousarray(ckpt[name]).astype(np.float32)).to(self.device).contiguous()
+        cat = lambda names: torch.cat([f32(n) for n in names], 0).contiguous()
+        g: List[Optional[torch.Tensor]] = [
+            f32("model.decoder.embed_tokens.weight"), f32("model.decoder.embed_positions.weight"),
+            f32("model.decoder.project_in.weight") if spec.has_proj else None,
+            f32("model.decoder.project_out.weight") if spec.has_proj else None,
+            f32("model.decoder.final_layer_norm.weight") if spec.has_final_ln else None,
+            f32("model.decoder.final_layer_norm.bias") if spec.has_final_ln else None,
+            f32("score.weight")]
+        for i in range(spec.num_hidden_layers):
+            p = f"model.decoder.layers.{i}."
+            qkv = [p + f"self_attn.{x}_proj" for x in "qkv"]
+            g += [cat([n + ".weight" for n in qkv]), cat([n + ".bias" for n in qkv]),
+                  f32(p + "self_attn.out_proj.weight"), f32(p + "self_attn.out_proj.bias"),
+                  f32(p + "self_attn_layer_norm.weight"), f32(p + "self_attn_layer_norm.bias"),
+                  f32(p + "fc1.weight"), f32(p + "fc1.bias"), f32(p + "fc2.weight"), f32(p + "fc2.bias"),
+                  f32(p + "final_layer_norm.weight"), f32(p + "final_layer_norm.bias")]
+        ptrs = (C.c_void_p * len(g))(*[(t.data_ptr() if t is not None else None) for t in g])
+        desc = _lib.ModelDesc(spec.vocab_size, spec.hidden_size, spec.ffn_dim, spec.num_hidden_layers,
+                              spec.num_attention_heads, spec.word_embed_proj_dim,
+                              spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
+                              1 if spec.do_layer_norm_before else 0, _lib.LTR_W_F32)
+        cfg = _lib.TrainConfig(lr, betas[0], betas[1], eps, weight_decay, _lib.LOSSES[loss], 1e-10, -1.0, dropout, seed)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ltr_train_create(C.byref(desc), ptrs, len(g), C.byref(cfg), self._stream(), C.byref(self._h)),
+                       "ltr_train_create")
+        del g                                    # the library copied the weights
+        self._n_weights = len(ptrs)
+        self._ws: Optional[torch.Tensor] = None
+        self.steps = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ltr_train_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ------------------------------------------------------------------ one step (trainer.py:137-165)
+    def step(self, ids: np.ndarray, cu_seqlens: np.ndarray, labels: Sequence[float],
+             shuffle: Optional[Sequence[int]] = None, apply_update: bool = True, return_logits: bool = False):
+        """``ids`` int64 [T] / ``cu_seqlens`` int32 [N+1]: the slate of prompts (already truncated to max_length);
+        ``labels`` [N]; ``shuffle``: listMLE's random permutation (listMLE.py:33; drawn here when None).
+        Returns the loss (float) [and the logits [N, num_labels] before the update]."""
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        N, T = cu.shape[0] - 1, int(cu[-1])
+        dev = self.device
+        ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(dev)
+        cu_d = torch.from_numpy(cu).to(dev)
+        lab_d = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.float32)).to(dev)
+        assert lab_d.numel() == N
+        sh_d = None
+        if self.loss == "listMLE":
+            sh = np.random.permutation(N) if shuffle is None else np.asarray(shuffle)
+            sh_d = torch.from_numpy(np.ascontiguousarray(sh, dtype=np.int32)).to(dev)
+        need = int(self.lib.ltr_train_workspace_bytes(self._h, N, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        logits = torch.empty(N, self.spec.num_labels, dtype=torch.float32, device=dev) if return_logits else None
+        _lib.check(self.lib.ltr_train_step(self._h, ids_d.data_ptr(), cu_d.data_ptr(), cu.ctypes.data, N, T, lab_d.data_ptr(),
+                                           sh_d.data_ptr() if sh_d is not None else None, 1 if apply_update else 0,
+                                           loss.data_ptr(), logits.data_ptr() if logits is not None else None,
+                                           self._ws.data_ptr(), self._ws.numel(), self._stream()), "ltr_train_step")
+        self.steps += 1
+        out = float(loss.item())
+        return (out, logits.cpu().numpy()) if return_logits else out
+
+    def step_lists(self, token_lists: Sequence[Sequence[int]], labels, **kw):
+        from .scorer import HipOPTScorer
+        ids, cu = HipOPTScorer.pack(token_lists)
+        return self.step(ids, cu, labels, **kw)
+
+    # ------------------------------------------------------------------ parameters
+    def _tensor(self, what: int, index: int) -> Optional[torch.Tensor]:
+        cnt = C.c_size_t()
+        _lib.check(self.lib.ltr_train_read(self._h, index, what, None, 0, C.byref(cnt), self._stream()), "ltr_train_read")
+        if not cnt.value:
+            return None
+        out = torch.empty(cnt.value, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ltr_train_read(self._h, index, what, out.data_ptr(), out.numel(), C.byref(cnt), self._stream()),
+                   "ltr_train_read")
+        return out
+
+    def _named(self, fn: int) -> Dict[str, np.ndarray]:
+        """HF-named f32 arrays (q, k, v unstacked)."""
+        s = self.spec
+        H, F, De = s.hidden_size, s.ffn_dim, s.word_embed_proj_dim
+        get = lambda i, shape: self._tensor(fn, i).view(*shape).cpu().numpy()
+        out = {"model.decoder.embed_tokens.weight": get(0, (s.vocab_size, De)),
+               "model.decoder.embed_positions.weight": get(1, (s.max_position_embeddings + s.POS_OFFSET, H))}
+        if s.has_proj:
+            out["model.decoder.project_in.weight"] = get(2, (H, De))
+            out["model.decoder.project_out.weight"] = get(3, (De, H))
+        if s.has_final_ln:
+            out["model.decoder.final_layer_norm.weight"] = get(4, (H,))
+            out["model.decoder.final_layer_norm.bias"] = get(5, (H,))
+        out["score.weight"] = get(6, (s.num_labels, De))
+        for i in range(s.num_hidden_layers):
+            b = _lib.LTR_WT_GLOBAL_COUNT + i * _lib.LTR_WL_COUNT
+            p = f"model.decoder.layers.{i}."
+            wqkv, bqkv = get(b + 0, (3 * H, H)), get(b + 1, (3 * H,))
+            for j, x in enumerate("qkv"):
+                out[p + f"self_attn.{x}_proj.weight"] = wqkv[j * H:(j + 1) * H]
+                out[p + f"self_attn.{x}_proj.bias"] = bqkv[j * H:(j + 1) * H]
+            out[p + "self_attn.out_proj.weight"] = get(b + 2, (H, H)); out[p + "self_attn.out_proj.bias"] = get(b + 3, (H,))
+            out[p + "self_attn_layer_norm.weight"] = get(b + 4, (H,)); out[p + "self_attn_layer_norm.bias"] = get(b + 5, (H,))
+            out[p + "fc1.weight"] = get(b + 6, (F, H)); out[p + "fc1.bias"] = get(b + 7, (F,))
+            out[p + "fc2.weight"] = get(b + 8, (H, F)); out[p + "fc2.bias"] = get(b + 9, (H,))
+            out[p + "final_layer_norm.weight"] = get(b + 10, (H,)); out[p + "final_layer_norm.bias"] = get(b + 11, (H,))
+        return out
+
+    def state(self) -> Dict[str, np.ndarray]:
+        """Current f32 master weights, HF names."""
+        return self._named(0)
+
+    def grads(self) -> Dict[str, np.ndarray]:
+        """Gradients of the last step, HF names."""
+        return self._named(1)
+
+    # ------------------------------------------------------------------ trainer.py:203-216
+    def save_pretrained(self, output_dir: str, config: Optional[PrefillPredictorConfig] = None) -> str:
+        """Writes ``<output_dir>/finetuned`` (HF directory, weights ``.half()``, trainer.py:213-216) and
+        ``<output_dir>/usage_config.json`` with ``model.path`` pointing at it (:203-211); returns the config path."""
+        from .opt_spec import tensor_shapes
+        fin = os.path.join(output_dir, "finetuned")
+        st = self.state()
+        save_hf_checkpoint(fin, self.spec, {k: st[k].astype(np.float16) for k, _ in tensor_shapes(self.spec)})
+        if config is None:
+            config = PrefillPredictorConfig(PrefillModelConfig(
+                pred_model="facebook/opt", num_labels=self.spec.num_labels,
+                mtype="rank" if self.spec.num_labels == 1 else "class", activation=None))
+        config.model.path = str(fin)
+        config.model.num_labels = self.spec.num_labels
+        path = os.path.join(output_dir, "usage_config.json")
+        PrefillPredictorConfig.to_json(config, path)
+        return path
