@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct ltr_model {
   int32_t* err_flag = nullptr;     // device word: bit 0 = a token id outside [0, vocab) was seen (ltr_status)
   bool prof_on = false;
   bool dbg_attn_valu = false;   // LTR_DEBUG_ATTN_VALU=1: f32 VALU attention inside the F16 mode (A/B for accuracy work)
+  std::mutex prof_mu;              // guards prof / prof_free: calls on one handle may come from several host threads
   std::vector<ProfRec> prof;       // records in use
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
   // F16 mode: library-owned slab-major images of the GEMM weights (launch_pack_weight), same index
@@ -141,6 +143,7 @@ struct ProfScope {
   int idx = -1;
   ProfScope(const ltr_model* cm, int kind, double work, hipStream_t st) : m(const_cast<ltr_model*>(cm)), s(st) {
     if (!m->prof_on) return;
+    std::lock_guard<std::mutex> lk(m->prof_mu);
     ProfRec r{};
     if (!m->prof_free.empty()) {
       r.start = m->prof_free.back().first; r.stop = m->prof_free.back().second; m->prof_free.pop_back();
@@ -152,7 +155,11 @@ struct ProfScope {
     m->prof.push_back(r);
     idx = (int)m->prof.size() - 1;
   }
-  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(m->prof[idx].stop, s); }
+  ~ProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(m->prof_mu);
+    (void)hipEventRecord(m->prof[idx].stop, s);
+  }
 };
 
 // one request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch
@@ -610,6 +617,7 @@ int ltr_profile_enable(ltr_handle h, int32_t on) {
 int ltr_profile_read(ltr_handle h, ltr_profile_stats* out, int32_t reset) {
   if (!h || !out) { set_error("ltr_profile_read: NULL argument"); return LTR_E_INVAL; }
   DeviceGuard guard(h->device);
+  std::lock_guard<std::mutex> lk(h->prof_mu);
   memset(out, 0, sizeof(*out));
   for (auto& r : h->prof) {
     LTR_HIP_CHECK(hipEventSynchronize(r.stop));

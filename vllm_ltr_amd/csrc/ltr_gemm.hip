@@ -126,16 +126,11 @@ constexpr int W_PLANE = BN16 * BK16;              // 16 KiB
 constexpr int STAGE = 2 * A_PLANE + W_PLANE;      // a_hi | a_lo | w = 32 KiB
 constexpr int CLD = 68;                           // f32 row stride of the epilogue strip
 constexpr int CROWS = 16;                         // rows per epilogue strip
-#ifndef LTR_MFMA16
-#define LTR_MFMA16 1
-#endif
-// chunk swizzle of tile row `row` (a function of (row >> 2) & 3), chosen per fragment shape so that the
-// 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct 16-B slots of a 256-B bank row:
-//   32x32x16 fragments (lane: row l & 31, chunk 2 ks + (l >> 5)):  q
-//   16x16x32 fragments (lane: row l & 15, chunk l >> 4):           (4 - q) & 3
+// chunk swizzle of tile row `row` (a function of (row >> 2) & 3), chosen for the 16x16x32 fragments (lane: row
+// l & 15, chunk l >> 4) so that the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct 16-B
+// slots of a 256-B bank row
 __device__ __forceinline__ int swz(int row) {
-  const int q = (row >> 2) & 3;
-  return LTR_MFMA16 ? ((4 - q) & 3) : q;
+  return (4 - ((row >> 2) & 3)) & 3;
 }
 __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
   return row * BK16 + ((kc ^ swz(row)) << 3);
@@ -205,7 +200,6 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
                                        (lds_void*)(base + 2 * A_PLANE + (wave * 32 + i * 16) * BK16), 16, 0, 0);
   };
 
-#if LTR_MFMA16
   // v_mfma_f32_16x16x32_f16: one instruction covers the whole 32-wide K-slab of a 16x16 block.  It
   // moves half as many accumulator bytes per FLOP through the register file as the 32x32x16 form
   // and, under the package power cap that bounds this kernel, sustains 15 % more FLOP/s
@@ -216,16 +210,6 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fk = lane >> 4;
-#else
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int frow = lane & 31, fk = lane >> 5;
-#endif
   const int nk = K / BK16;
 #ifdef LTR_GEMM_TIMELINE
   unsigned long long tl_dma = 0, tl_bar = 0;
@@ -273,7 +257,6 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const __half* s_ahi = smem + (kt & 1) * STAGE;
     const __half* s_alo = s_ahi + A_PLANE;
     const __half* s_w = s_ahi + 2 * A_PLANE;
-#if LTR_MFMA16
     {
       f16x8 ah[4], al[4], bw[4];
 #pragma unroll
@@ -292,43 +275,18 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
         }
     }
-#else
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kc = ks * 2 + fk;
-      f16x8 ah[2], al[2], bw[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wr * 64 + i * 32 + frow;
-        ah[i] = *reinterpret_cast<const f16x8*>(s_ahi + lds_off_h(row, kc));
-        al[i] = *reinterpret_cast<const f16x8*>(s_alo + lds_off_h(row, kc));
-        const int col = wc * 64 + i * 32 + frow;
-        bw[i] = *reinterpret_cast<const f16x8*>(s_w + lds_off_h(col, kc));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
-        }
-    }
-#endif
   }
 
 #ifdef LTR_GEMM_TIMELINE
   const unsigned long long tl1 = __builtin_readcyclecounter();
 #endif
   // ---- epilogue through LDS: per-wave strip [16 rows][64 cols] f32 (row stride CLD), four
-  // strips per wave (two 32-row MFMA tiles x their two 16-row halves = registers 0-7 / 8-15).
+  // strips per wave (its four 16-row MFMA blocks).
   // Each wave touches only its own strip, so after ONE workgroup barrier (the K-loop's LDS reads
   // are done) the strips are wave-local: LDS executes a wave's instructions in order, an
   // s_waitcnt between the writes and the transposed reads is all the synchronisation needed.
   // Read-back: a lane owns 8 consecutive columns -> 16-B stores for f32 and for each fp16 plane.
   float* s_c = reinterpret_cast<float*>(smem) + wave * CROWS * CLD;
-#if !LTR_MFMA16
-  const int lq = lane & 31, lh = lane >> 5;
-#endif
   // Column ownership of a lane in the read-back (two float4 per row): split outputs need 8 CONSECUTIVE
   // columns (one 16-byte store per fp16 plane: 8 lanes = a 128-B row piece); f32-only outputs take columns
   // 4k..4k+3 and 32+4k..32+4k+3 instead, so that each of the two f32 stores / residual loads of the 8 lanes
@@ -354,20 +312,11 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   __syncthreads();
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
-    const int i = st >> 1, half = st & 1;
-#if LTR_MFMA16
     // 16x16 C layout: col = lane & 15, row = 4 * (lane >> 4) + e; strip st = the wave's 16-row block st
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) s_c[(4 * (lane >> 4) + e) * CLD + j * 16 + (lane & 15)] = acc[st][j][e];
-#else
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 8; ++r)   // register 8*half + r -> strip row (r & 3) + 8 * (r >> 2) + 4 * lh
-        s_c[((r & 3) + 8 * (r >> 2) + 4 * lh) * CLD + j * 32 + lq] = acc[i][j][8 * half + r];
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (ccol < N) {
@@ -378,7 +327,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int srow = it * 8 + erow;
-        const int grow = m0 + wr * 64 + i * 32 + half * 16 + srow;
+        const int grow = m0 + wr * 64 + st * 16 + srow;
         ok[it] = grow < M;
         gr[it] = grow;
         o[it] = (size_t)grow * N + ccol;

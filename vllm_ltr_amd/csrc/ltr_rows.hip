@@ -60,51 +60,72 @@ __device__ __forceinline__ void store8_split(__half* hi, __half* lo, const float
 
 // hidden[t,:] = E_tok[ids[t],:] + E_pos[pos(t)+2,:]                      (De == H)
 // hidden[t,:] = E_pos[pos(t)+2,:];  tok_out[t,:] = E_tok[ids[t],:]       (De != H)
+// One wave owns EG_ROWS consecutive token rows: ONE binary search in cu_seqlens per wave (the following rows walk
+// forward from it), and the gathers of all its rows are in flight before the first store - with one row per wave a
+// wave spent ~13 dependent L2 round trips on the search before it issued its first table read.
+constexpr int EG_ROWS = 4;
 template <typename WT, bool PROJ>
 __global__ void __launch_bounds__(256) embed_gather_kernel(
     const int64_t* __restrict__ ids, const int32_t* __restrict__ cu, int n_req, int T, int tok_off,
     const WT* __restrict__ tok_table, int De, int vocab, const WT* __restrict__ pos_table, int H,
     int pos_rows, float* __restrict__ hidden, void* tok_hi, void* tok_lo, int32_t* __restrict__ err_flag) {
   const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);   // row inside this chunk
-  if (t >= T) return;
-  const int tg = tok_off + t;                                        // global token index
-  const int req = find_request(cu, n_req, tg);
-  int pos = tg - cu[req] + 2;                                        // opt.py:43-53 offset
-  pos = min(pos, pos_rows - 1);
-  long long id = ids[tg];
-  if (id < 0 || id >= vocab) {
-    // F.embedding raises here (vocab_parallel_embedding.py:95-106).  Flag it for ltr_status and read a valid
-    // row instead of faulting; the scores of this call are invalid.
-    if (lane == 0 && err_flag != nullptr) atomicOr(err_flag, 1);
-    id = id < 0 ? 0 : vocab - 1;
+  const int t0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * EG_ROWS;   // first row of this wave inside the chunk
+  if (t0 >= T) return;
+  const int nrow = min(EG_ROWS, T - t0);
+  int req = find_request(cu, n_req, tok_off + t0);
+  int req_beg = cu[req], req_end = cu[req + 1];
+  const WT* trow[EG_ROWS];
+  const WT* prow[EG_ROWS];
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < EG_ROWS; ++r) {
+    const int tg = tok_off + min(t0 + r, T - 1);                       // global token index (clamped: unused rows repeat the last)
+    while (tg >= req_end) { ++req; req_beg = req_end; req_end = cu[req + 1]; }   // wave-uniform walk
+    const int pos = min(tg - req_beg + 2, pos_rows - 1);               // opt.py:43-53 offset
+    long long id = ids[tg];
+    if (id < 0 || id >= vocab) {
+      // F.embedding raises here (vocab_parallel_embedding.py:95-106).  Flag it for ltr_status and read a valid
+      // row instead of faulting; the scores of this call are invalid.
+      bad = true;
+      id = id < 0 ? 0 : vocab - 1;
+    }
+    trow[r] = tok_table + (size_t)id * De;
+    prow[r] = pos_table + (size_t)pos * H;
   }
-  const WT* trow = tok_table + (size_t)id * De;
-  const WT* prow = pos_table + (size_t)pos * H;
-  float* hrow = hidden + (size_t)t * H;
+  if (bad && lane == 0 && err_flag != nullptr) atomicOr(err_flag, 1);
   if (!PROJ) {
     // 4 columns per lane: every f32 store instruction writes 1 KiB of contiguous line-complete memory
     // (8 columns per lane = two float4 stores that interleave in 16-byte pieces)
     for (int c = lane * 4; c < H; c += 256) {
-      float a[4], b[4];
-      Vec4<WT>::load(trow + c, a);
-      Vec4<WT>::load(prow + c, b);
-      *reinterpret_cast<float4*>(hrow + c) = make_float4(a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]);
+      float a[EG_ROWS][4], b[EG_ROWS][4];
+#pragma unroll
+      for (int r = 0; r < EG_ROWS; ++r) { Vec4<WT>::load(trow[r] + c, a[r]); Vec4<WT>::load(prow[r] + c, b[r]); }
+#pragma unroll
+      for (int r = 0; r < EG_ROWS; ++r)
+        if (r < nrow)
+          *reinterpret_cast<float4*>(hidden + (size_t)(t0 + r) * H + c) =
+              make_float4(a[r][0] + b[r][0], a[r][1] + b[r][1], a[r][2] + b[r][2], a[r][3] + b[r][3]);
     }
   } else {
     for (int c = lane * 8; c < H; c += 512) {
-      float b[8];
-      Vec8<WT>::load(prow + c, b);
-      store8_f32(hrow + c, b);
+      float b[EG_ROWS][8];
+#pragma unroll
+      for (int r = 0; r < EG_ROWS; ++r) Vec8<WT>::load(prow[r] + c, b[r]);
+#pragma unroll
+      for (int r = 0; r < EG_ROWS; ++r)
+        if (r < nrow) store8_f32(hidden + (size_t)(t0 + r) * H + c, b[r]);
     }
     for (int c = lane * 8; c < De; c += 512) {
-      float a[8];
-      Vec8<WT>::load(trow + c, a);
-      if (sizeof(WT) == 2) {
-        // table values are fp16 already: hi = value, lo = 0
-        store8_split((__half*)tok_hi + (size_t)t * De + c, (__half*)tok_lo + (size_t)t * De + c, a);
-      } else {
-        store8_f32((float*)tok_hi + (size_t)t * De + c, a);
+      float a[EG_ROWS][8];
+#pragma unroll
+      for (int r = 0; r < EG_ROWS; ++r) Vec8<WT>::load(trow[r] + c, a[r]);
+#pragma unroll
+      for (int r = 0; r < EG_ROWS; ++r) {
+        if (r >= nrow) continue;
+        const size_t o = (size_t)(t0 + r) * De + c;
+        if (sizeof(WT) == 2) store8_split((__half*)tok_hi + o, (__half*)tok_lo + o, a[r]);   // fp16 table values: hi = value, lo = 0
+        else store8_f32((float*)tok_hi + o, a[r]);
       }
     }
   }
@@ -216,7 +237,7 @@ int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N
                         float* hidden_out, AOp tok_out, int32_t* err_flag, hipStream_t s) {
   if (T == 0) return LTR_OK;
   if ((H % 8) || (De % 8)) { set_error("embed_gather: H and De must be multiples of 8"); return LTR_E_INVAL; }
-  dim3 grid((T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  dim3 grid((T + ROWS_PER_BLOCK * EG_ROWS - 1) / (ROWS_PER_BLOCK * EG_ROWS));
   const bool proj = De != H;
   if (wdtype == LTR_W_F16) {
     if (proj) embed_gather_kernel<__half, true><<<grid, 256, 0, s>>>(ids, cu, N, T, tok_off, (const __half*)tok_table, De, vocab, (const __half*)pos_table, H, pos_rows, hidden_out, tok_out.hi, tok_out.lo, err_flag);
