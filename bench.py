@@ -190,6 +190,32 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # The GEMM launches of the default build also carry the LayerNorm work (LayerNorm fold, ltr_gemm.hip), so their
+    # FLOP rate is not comparable with a plain GEMM's.  For the record, time the same call once more on a second handle
+    # with the fold off (LTR_NO_LN_FOLD is read at ltr_create): `roofline.unfused` below.  Outside the timed region.
+    unfused = None
+    if rank == 0 and args.weight_dtype == "f16" and spec.do_layer_norm_before and os.environ.get("LTR_NO_LN_FOLD") != "1":
+        os.environ["LTR_NO_LN_FOLD"] = "1"
+        try:
+            sc2 = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)
+        finally:
+            del os.environ["LTR_NO_LN_FOLD"]
+        tmp = torch.empty(my_r1 - my_r0, dtype=torch.float32, device=dev)
+        cu_loc = np.ascontiguousarray(cu[my_r0:my_r1 + 1] - cu[my_r0]).astype(np.int32)
+        ids_loc, cu_loc_d = ids_d[int(cu[my_r0]):int(cu[my_r1])], torch.from_numpy(cu_loc).to(dev)
+        sc2.score_device(ids_loc, cu_loc_d, cu_loc, out=tmp)
+        sc2.profile(True); sc2.profile_read(reset=True)
+        t_u = time.perf_counter()
+        for _ in range(2):
+            sc2.score_device(ids_loc, cu_loc_d, cu_loc, out=tmp)
+        torch.cuda.synchronize()
+        t_u = (time.perf_counter() - t_u) / 2
+        pu = sc2.profile_read(reset=True)
+        unfused = dict(ms_per_forward=t_u * 1e3, gemm_ms=pu["gemm"]["ms"] / 2, ln_ms=pu["ln"]["ms"] / 2,
+                       gemm_tflops=pu["gemm"]["work"] / (pu["gemm"]["ms"] * 1e-3) / 1e12,
+                       frac=pu["gemm"]["work"] / (pu["gemm"]["ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS)
+        sc2.close(); del sc2, tmp
+    barrier()
     scorer.profile(True)
     scorer.profile_read(reset=True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -292,7 +318,11 @@ def main():
                          "unit": "TFLOP/s", "frac": gemm_tflops / (PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3),
                          "traffic": traffic,
                          "launches_per_step": gemm["launches"] // max(args.steps, 1),
-                         "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1)},
+                         "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
+                         "note": "the GEMM launches also carry the LayerNorm work of the layer (LayerNorm fold: operand + row "
+                                 "statistics in the producer epilogue, normalisation in the consumer epilogue); "
+                                 "`unfused` = the same forward with separate LayerNorm launches (LTR_NO_LN_FOLD=1)",
+                         "unfused": unfused},
             "kernels": kernels,
             "model_tflop_per_step": (lin + att) / 1e12,
         }

@@ -10,5 +10,5 @@ python - "$out" <<'PY'
 import json, sys
 for line in open(sys.argv[1]):
     d = json.loads(line)
-    print(f"N={d['config']['queue_per_gpu']:6d} T={d['config']['tokens_per_gpu']:8d}  {d['value']:9.0f} req/s  cold p50 {d['p50_rank_latency_ms']:8.2f} ms  steady {d['p50_steady_rank_latency_ms']*1e3:7.1f} us  gemm {d['roofline']['achieved']:.0f} TF")
+    print(f"N={d['config']['queue_per_gpu']:6d} T={d['config']['tokens_total']:8d}  {d['value']:9.0f} req/s  cold p50 {d['p50_rank_latency_ms']:8.2f} ms  steady {d['p50_steady_rank_latency_ms']*1e3:7.1f} us  gemm {d['roofline']['achieved']:.0f} TF")
 PY
