@@ -36,8 +36,8 @@ def _stale(target: str, deps) -> bool:
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(HERE, src.replace(".hip", ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
-    if force or _stale(obj, deps):
-        extra = os.environ.get("LTR_FLAGS_" + src.split(".")[0].upper(), "").split()     # experiments: LTR_FLAGS_LTR_GEMM="..."
+    extra = os.environ.get("LTR_FLAGS_" + src.split(".")[0].upper(), "").split()     # experiments: LTR_FLAGS_LTR_GEMM="..."
+    if force or extra or _stale(obj, deps):
         cmd = [HIPCC, *FLAGS, *PER_FILE_FLAGS.get(src, []), *extra, "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -271,7 +271,9 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifndef LTR_EXP_NO_LO    // perf probe (wrong results): what the lo pass costs
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+#endif
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -367,8 +369,13 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
           const size_t os = ep.out_slab ? slab_off(gr[it], ccol, M) : o[it];
-          *reinterpret_cast<uint4*>((__half*)ep.out_hi + os) = *reinterpret_cast<const uint4*>(h);
-          *reinterpret_cast<uint4*>((__half*)ep.out_lo + os) = *reinterpret_cast<const uint4*>(l);
+#ifdef LTR_GEMM_NOSTORE   // diag: epilogue without its global stores (keeps the values alive through a never-true branch)
+          if (h[0] == __half(12345.f) && l[7] == __half(54321.f))
+#endif
+          {
+            *reinterpret_cast<uint4*>((__half*)ep.out_hi + os) = *reinterpret_cast<const uint4*>(h);
+            *reinterpret_cast<uint4*>((__half*)ep.out_lo + os) = *reinterpret_cast<const uint4*>(l);
+          }
         }
         if (LNM == LNP) {
           // x[0..7] = columns ccol..+3 and ccol+32..+35 of the f32 row just stored (wide ownership: the 8 lanes of a
