@@ -48,11 +48,16 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
   const int q = nwg / NXCD, r = nwg % NXCD;
   const int xcd = bid % NXCD, k = bid / NXCD;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  const int per_group = GM * tiles_n;
+  const int per_group = (GM & 0xffff) * tiles_n;
   const int g = lin / per_group, in_g = lin - g * per_group;
-  const int gm = min(GM, tiles_m - g * GM);          // last group may be short
-  tm = g * GM + in_g % gm;
-  tn = in_g / gm;
+  const int gm = min(GM & 0xffff, tiles_m - g * (GM & 0xffff));          // last group may be short
+  if (GM >> 16) {        // N fastest inside the group (narrow outputs, see launch_gemm)
+    tm = g * (GM & 0xffff) + in_g / tiles_n;
+    tn = in_g % tiles_n;
+  } else {
+    tm = g * GM + in_g % gm;
+    tn = in_g / gm;
+  }
 }
 
 struct Epilogue {
@@ -594,7 +599,15 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   if (g.out_slab && g.N % 32) { set_error("gemm: slab-major output needs N %% 32 == 0"); return LTR_E_INVAL; }
   dim3 grid(tiles_m * tiles_n);
   if (wdtype == LTR_W_F16) {
-    static const int gm = [] { const char* e = getenv("LTR_GEMM_GM"); return e ? atoi(e) : GM_DEFAULT; }();   // diag knob
+    // Order inside a group of 8 row tiles: M fastest for wide outputs (QKV, fc1: 9-12 column tiles; consecutive
+    // workgroups share a weight panel), N fastest for narrow ones (out_proj, fc2: <= 4 column tiles; the column tiles of
+    // a row start together and share its activation panel - at K = 3072 a panel is 1.5 MB and the L2 holds ~2 us of
+    // the XCD's stream, so only tiles in lockstep share).  Measured: -2 ms per call for the narrow shapes, +2 ms if
+    // applied to the wide ones (profiles/r02_ab_gemm_gm.txt).  LTR_GEMM_GM / LTR_GEMM_GM_NARROW: diag overrides
+    // (group size; + 65536 = N fastest).
+    static const int gm_wide = [] { const char* e = getenv("LTR_GEMM_GM"); return e ? atoi(e) : GM_DEFAULT; }();
+    static const int gm_narrow = [] { const char* e = getenv("LTR_GEMM_GM_NARROW"); return e ? atoi(e) : (GM_DEFAULT | 65536); }();
+    const int gm = tiles_n <= 4 ? gm_narrow : gm_wide;
     if (lnm == LNP)
       gemm_f16s_kernel<LNP><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
                                                  g.N, g.K, tiles_m, tiles_n, gm, ep);
