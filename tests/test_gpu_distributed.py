@@ -19,6 +19,45 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _worker_125m(rank, world, port, q):
+    """BASELINE config 4 in miniature: the OPT-125m predictor, a ShareGPT-profile queue, request-sharded over the ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from util import bench_lengths
+        from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
+        from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+        from vllm_ltr_amd.rank import DeviceQueue
+        from vllm_ltr_amd.scorer import HipOPTScorer
+        dev = torch.device("cuda:0")
+        spec = OPTSpec.opt_125m()
+        sc = HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
+        n = 3000
+        lens = bench_lengths(n, seed=7)
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(4, spec.vocab_size, (int(lens.sum()),), generator=g, dtype=torch.int64).numpy()
+        cu = np.zeros(n + 1, np.int32); np.cumsum(lens, out=cu[1:]); ids[cu[:-1]] = 2
+        ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+        single = sc.score_device(ids_d, cu_d, cu).cpu().numpy() if rank == 0 else None
+        got = ShardedScorer(sc, dev, min_requests_to_shard=1024).score_device(ids_d, cu_d, cu)
+        b = shard_bounds(cu, world)
+        tok = [int(cu[y] - cu[x]) for x, y in b]
+        queue = DeviceQueue(dev, starv=200, period=10, capacity=n)
+        queue.append(got)
+        need = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        perm, n_sel, _, _ = queue.step(need, torch.ones(n, dtype=torch.int32, device=dev), 2048, 256)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (perm.cpu().numpy().tolist(), int(n_sel.item())))
+        same = all(x == gathered[0] for x in gathered)
+        ok = True if single is None else bool(np.array_equal(got.cpu().numpy(), single))
+        q.put((rank, ok, same, tok))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -91,3 +130,23 @@ def test_two_process_sharded_hip_scoring_on_one_device():
         assert same and head, f"rank {rank}: ranks disagree on the permutation"
         assert 0 < bounds[1] - bounds[0] < 700
     assert res[0][4][1] == res[1][4][0]          # contiguous shards
+
+
+def test_config4_shape_two_ranks_opt125m():
+    """OPT-125m, 3,000-request ShareGPT-profile queue sharded over two ranks (one device): token-balanced shards, gathered
+    scores bit-identical to rank 0's single-process scores, identical rank step + budget selection on both ranks."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_125m, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, same, tok in res:
+        assert ok and same, (rank, ok, same)
+        assert abs(tok[0] - tok[1]) <= 2048          # token-balanced within one maximal request

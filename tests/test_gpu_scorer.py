@@ -436,3 +436,66 @@ def test_handle_of_another_device_is_usable(dev):
     if torch.cuda.device_count() > 1:
         sc1 = _scorer(spec, seeded_checkpoint(spec, 8), "cuda:1", "f16")
         assert np.array_equal(sc1.score(ids, cu), sc.score(ids, cu)) and torch.cuda.current_device() == before
+
+
+def test_plugin_slot_reclamation_mirror_and_adoption(dev):
+    """Long-running queue behind the plug-in: thousands of arrivals and departures through a small live set so that slots
+    are reclaimed and reused (the counters of a reused slot must restart at zero, scheduler.py:372-374); mirror_host=True
+    writes pri / idle / runs back every step like the reference's loops; requests scored before the ranker saw them are
+    adopted with their host state."""
+    from collections import deque
+    from oracle import rank_step as rs
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+
+    spec = OPTSpec.tiny_pre_ln()
+    sc = _scorer(spec, seeded_checkpoint(spec, 4), dev, "f16")
+    ranker = MI355XRanker(sc, "opt-xxx-starv2-period1", max_length=100, mirror_host=True)
+    r = np.random.RandomState(5)
+    nid = [0]
+
+    def mk():
+        nid[0] += 1
+        return FakeSeqGroup(str(nid[0]), [2] + r.randint(4, spec.vocab_size, r.randint(1, 12)).tolist())
+
+    class Sched:
+        pass
+    s = Sched()
+    s.waiting, s.running, s.swapped = deque(mk() for _ in range(30)), deque(), deque()
+    # three requests that some other component scored and aged already
+    for g, (p, i, u) in zip(list(s.waiting)[:3], [(-1, 0, 1), (0, 5, 0), (0, 1, 0)]):
+        g.aux_model_score, g.pri, g.idle, g.runs = float(r.standard_normal()), p, i, u
+    ranker.install(s)
+    mirror = {}
+    peak_slots = 0
+    for step in range(260):
+        order = s._get_ordered_requests()
+        reqs = list(s.waiting) + list(s.running) + list(s.swapped)
+        for g in reqs:
+            if g.request_id not in mirror:
+                mirror[g.request_id] = rs.Req(g.request_id, g.aux_model_score)
+        if step == 0:                                        # adopted host state (before this step's promote/demote)
+            for g, (p, i, u) in zip(reqs[:3], [(-1, 0, 1), (0, 5, 0), (0, 1, 0)]):
+                mirror[g.request_id].pri, mirror[g.request_id].idle, mirror[g.request_id].runs = p, i, u
+        lit = rs.opt_order([mirror[g.request_id] for g in reqs], 2, 1)
+        assert [g.request_id for g in order] == [m.request_id for m in lit], step
+        assert all((g.pri, g.idle, g.runs) == (mirror[g.request_id].pri, mirror[g.request_id].idle, mirror[g.request_id].runs)
+                   for g in reqs), step                      # mirror_host: the objects follow the device state
+        ran = order[:6]
+        for g in ran:
+            if g in s.waiting:
+                s.waiting.remove(g); s.running.append(g)
+        all_pri = list(s.swapped) + list(s.running) + list(s.waiting)
+        ranker.age(all_pri, ran)
+        ran_ids = {g.request_id for g in ran}
+        rs.age_update([mirror[g.request_id] for g in all_pri], [mirror[g.request_id] for g in all_pri if g.request_id in ran_ids])
+        assert all((g.pri, g.idle, g.runs) == (mirror[g.request_id].pri, mirror[g.request_id].idle, mirror[g.request_id].runs)
+                   for g in all_pri), step
+        for _ in range(5):                                   # five departures and five arrivals per step: the live set stays ~30
+            if s.running:
+                s.running.popleft()
+        for _ in range(5):
+            s.waiting.append(mk())
+        peak_slots = max(peak_slots, ranker.queue.n)
+    assert nid[0] > 1300 and peak_slots < 1300              # slots were reclaimed and reused (one per live request + slack)
+    assert nid[0] - 10 <= ranker.stats["requests_scored"] <= nid[0] - 3      # everything but the 3 adopted (and the last arrivals)
