@@ -499,3 +499,28 @@ def test_plugin_slot_reclamation_mirror_and_adoption(dev):
         peak_slots = max(peak_slots, ranker.queue.n)
     assert nid[0] > 1300 and peak_slots < 1300              # slots were reclaimed and reused (one per live request + slack)
     assert nid[0] - 10 <= ranker.stats["requests_scored"] <= nid[0] - 3      # everything but the 3 adopted (and the last arrivals)
+
+
+def test_layernorm_fold_on_and_off_agree(dev, monkeypatch):
+    """The LayerNorm fold (default for pre-LN fp16 models: operand + row statistics from the producing GEMM's epilogue,
+    normalisation in the consuming GEMM's epilogue) against the same forward with separate LayerNorm launches
+    (LTR_NO_LN_FOLD=1, read by ltr_create), both against the oracle - including rows with a large mean / std ratio, where
+    the fold's `acc - mean c` cancels."""
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 12)
+    w = ckpt["model.decoder.embed_positions.weight"].astype(np.float32)
+    w += 0.5                                              # every residual row gets mean ~ 0.5 against std ~ 0.03
+    ckpt["model.decoder.embed_positions.weight"] = w.astype(np.float16)
+    ids, cu = synthetic_batch(spec, [1, 2, 17, 64, 65, 128, 150, 33], 13)
+    folded = _scorer(spec, ckpt, dev, "f16")
+    monkeypatch.setenv("LTR_NO_LN_FOLD", "1")
+    plain = _scorer(spec, ckpt, dev, "f16")
+    monkeypatch.delenv("LTR_NO_LN_FOLD")
+    a, b = folded.score(ids, cu), plain.score(ids, cu)
+    want = OracleOPTScorer(spec, ckpt, dtype=torch.float64).score(ids, cu)
+    ea, eb = float(np.abs(a - want).max()), float(np.abs(b - want).max())
+    print(f"LayerNorm fold: max|d| vs f64 oracle {ea:.2e} (folded), {eb:.2e} (separate launches)")
+    assert ea <= 2e-5 and eb <= 2e-5
+    folded.profile(True); folded.profile_read(True); folded.score(ids, cu)
+    plain.profile(True); plain.profile_read(True); plain.score(ids, cu)
+    assert folded.profile_read()["ln"]["launches"] == 1 and plain.profile_read()["ln"]["launches"] == 2 * spec.num_hidden_layers
