@@ -291,6 +291,13 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        pmc = None
+        ppath = os.path.join(ROOT, "profiles", "gemm_pmc.json")
+        if os.path.exists(ppath):
+            try:
+                pmc = json.load(open(ppath)).get("gemm_f16s_kernel")
+            except Exception:
+                pmc = None
         out = {
             "metric": "requests ranked/sec (cold call: OPT predictor forward + priority sort/aging)",
             "value": n_total * args.steps / elapsed,
@@ -319,7 +326,10 @@ def main():
                          "note": "the GEMM launches also carry the LayerNorm work of the layer (LayerNorm fold: operand + row "
                                  "statistics in the producer epilogue, normalisation in the consumer epilogue); "
                                  "`unfused` = the same forward with separate LayerNorm launches (LTR_NO_LN_FOLD=1)",
-                         "unfused": unfused},
+                         "unfused": unfused,
+                         # MFMA pipe utilisation / L2 hit rate of the kernel from the last PMC passes (profiles/gemm_pmc.json,
+                         # diag/refresh_profiles.sh); null when the file is absent
+                         "pmc": pmc},
             "kernels": kernels,
             "model_tflop_per_step": (lin + att) / 1e12,
         }

@@ -26,6 +26,8 @@ db() { find $O/$1 -name "*.db" | head -1; }
 python profiles/make_traffic.py $(db pmc_fetch) $(db pmc_write) $(db calib_fetch) $(db calib_write) $O/kernel_traffic.json > $O/traffic.log 2>&1
 cp profiles/gemm_traffic.json $O/gemm_traffic.json
 python profiles/summarize_pmc.py $(db pmc_sq) $(db pmc_l2) > $O/pmc_sq.txt 2>&1
+python profiles/make_gemm_pmc.py $(db pmc_sq) $(db pmc_l2) $O/gemm_pmc.json > /dev/null 2>&1
+cp $O/gemm_pmc.json profiles/gemm_pmc.json
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1
