@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--weight-dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--chunk-tokens", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unfused", action="store_true",
+                    help="skip the extra forward with separate LayerNorm launches (roofline.unfused): keeps a rocprofv3 "
+                         "trace / PMC pass of this command to the launches of the timed configuration")
     ap.add_argument("--starv", type=int, default=200)
     ap.add_argument("--period", type=int, default=10)
     ap.add_argument("--steady-new", type=int, default=0,
@@ -194,7 +197,8 @@ def main():
     # FLOP rate is not comparable with a plain GEMM's.  For the record, time the same call once more on a second handle
     # with the fold off (LTR_NO_LN_FOLD is read at ltr_create): `roofline.unfused` below.  Outside the timed region.
     unfused = None
-    if rank == 0 and args.weight_dtype == "f16" and spec.do_layer_norm_before and os.environ.get("LTR_NO_LN_FOLD") != "1":
+    if rank == 0 and args.weight_dtype == "f16" and spec.do_layer_norm_before and not args.no_unfused \
+            and os.environ.get("LTR_NO_LN_FOLD") != "1":
         os.environ["LTR_NO_LN_FOLD"] = "1"
         try:
             sc2 = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)

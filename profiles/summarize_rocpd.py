@@ -24,6 +24,16 @@ def main(db, out):
             w.writerow([r[0], r[1], int(r[2]), f"{r[3]:.1f}", int(r[4]), int(r[5]), f"{100.0 * r[2] / total:.2f}"])
     for r in rows[:14]:
         print(f"{100.0 * r[2] / total:6.2f}%  calls={r[1]:6d}  avg={r[3] / 1e3:9.1f}us  {r[0][:90]}")
+    # template instances of one kernel taken together (gemm_f16s_kernel<0|1|2>: plain / LayerNorm producer / consumer epilogue)
+    import re
+    comb = {}
+    for r in rows:
+        m = re.search(r"(\w+)<[^(]*>\(", r[0])
+        if m:
+            c = comb.setdefault(m.group(1), [0, 0])
+            c[0] += r[1]; c[1] += r[2]
+    for k, (n, t) in comb.items():
+        print(f"combined {k}<*>: calls={n} avg={t / n / 1e3:.1f}us total={t / 1e6:.2f}ms")
 
 
 if __name__ == "__main__":
