@@ -75,16 +75,22 @@ __device__ __forceinline__ uint64_t key_of(const float* __restrict__ score, cons
 // see each other's updates), the next chunk's keys are built in registers while the current one is counted
 // (the two dependent L2 round trips of members -> state hide behind the compares), each wave counts 1/NW of
 // the chunk for the same 64 positions, and perm is written directly.
-template <int NW>
+template <int NW, int IT>
 __global__ void __launch_bounds__(NW * 64) rank_fused_kernel(
     const float* __restrict__ score, const int32_t* __restrict__ pri, const int32_t* __restrict__ idle,
     const int32_t* __restrict__ runs, const uint32_t* __restrict__ tiebreak, const int32_t* __restrict__ members, int N,
     int starv, int period, uint32_t flags, int32_t* __restrict__ perm) {
+  // IT = 64: a lane owns one of the workgroup's 64 positions and counts its wave's whole share of the chunk;
+  // IT = 32: the workgroup owns 32 positions (twice as many workgroups: 256 at 8k requests = every CU), lane and lane ^ 32
+  // own the same position and count one half of the wave's share each
   constexpr int T = NW * 64;                    // threads = keys staged per chunk
+  constexpr int SHARE = 64 * 64 / IT / (64 / IT);   // keys of a chunk a wave looks at = T / NW = 64
+  constexpr int PER_LANE = SHARE * IT / 64;     // ... of which one lane counts 64 (IT = 64) or 32 (IT = 32)
   __shared__ uint64_t skeys[2][T];
   __shared__ int32_t spart[T];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
+  const int i = blockIdx.x * IT + (lane & (IT - 1));
+  const int sub = IT == 64 ? 0 : (lane >> 5) * PER_LANE;
   const uint64_t ki = (i < N) ? key_of(score, pri, idle, runs, tiebreak, members, i, starv, period, flags) : 0ull;
   int cnt = 0;
   uint64_t nxt = (threadIdx.x < N) ? key_of(score, pri, idle, runs, tiebreak, members, threadIdx.x, starv, period, flags) : ~0ull;
@@ -94,13 +100,14 @@ __global__ void __launch_bounds__(NW * 64) rank_fused_kernel(
     __syncthreads();                            // chunk j0 is staged; the other buffer is free again
     const int jn = j0 + T + threadIdx.x;
     nxt = (jn < N) ? key_of(score, pri, idle, runs, tiebreak, members, jn, starv, period, flags) : ~0ull;
-    const uint64_t* sk = skeys[buf] + wave * 64;
+    const uint64_t* sk = skeys[buf] + wave * 64 + sub;
 #pragma unroll 16
-    for (int jj = 0; jj < 64; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
+    for (int jj = 0; jj < PER_LANE; ++jj) cnt += (sk[jj] < ki) ? 1 : 0;
   }
+  if (IT == 32) cnt += __shfl_xor(cnt, 32, 64);
   spart[threadIdx.x] = cnt;
   __syncthreads();
-  if (wave == 0 && i < N) {
+  if (wave == 0 && lane < IT && i < N) {
     int total = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) total += spart[w * 64 + lane];
@@ -644,7 +651,9 @@ int rank_nw() { static int m = [] { const char* e = getenv("LTR_RANK_NW"); retur
 int launch_rank_small(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
                       const int32_t* members, int N, int starv, int period, uint32_t flags, int32_t* perm_out,
                       void* ws, size_t ws_bytes, bool* applied, hipStream_t s) {
-  const int grid = (N + 63) / 64, nw = rank_nw();
+  const int nw = rank_nw();
+  static const int it = [] { const char* e = getenv("LTR_RANK_IT"); return e ? atoi(e) : 32; }();   // diag: positions per workgroup
+  int grid = (N + 63) / 64;
   if (rank_mode() == 1 && ws != nullptr && ws_bytes >= rank_workspace_bytes(N)) {
     int64_t n64 = ((int64_t)N + 63) / 64 * 64;
     uint64_t* keys = (uint64_t*)ws;
@@ -659,9 +668,13 @@ int launch_rank_small(const float* scores, int32_t* pri, int32_t* idle, int32_t*
     *applied = true;
     return LTR_OK;
   }
-  if (nw == 4) rank_fused_kernel<4><<<grid, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
-  else if (nw == 8) rank_fused_kernel<8><<<grid, 512, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
-  else rank_fused_kernel<16><<<grid, 1024, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  if (it == 32) {
+    grid = (N + 31) / 32;
+    if (nw == 8) rank_fused_kernel<8, 32><<<grid, 512, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+    else rank_fused_kernel<16, 32><<<grid, 1024, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  } else if (nw == 4) rank_fused_kernel<4, 64><<<grid, 256, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  else if (nw == 8) rank_fused_kernel<8, 64><<<grid, 512, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
+  else rank_fused_kernel<16, 64><<<grid, 1024, 0, s>>>(scores, pri, idle, runs, tiebreak, members, N, starv, period, flags, perm_out);
   LTR_LAUNCH_CHECK();
   *applied = false;
   return LTR_OK;

@@ -158,6 +158,9 @@ class DeviceQueue:
         self.starv, self.period = int(starv), int(period)
         self.n = 0                          # high-water mark of slots handed out
         self._free: list = []
+        self._out = None
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._alloc(capacity)
         self.ws = RankWorkspace(self.device)
 
@@ -243,18 +246,26 @@ class DeviceQueue:
         s, p, i, r = self._view(members)
         N = members.numel() if members is not None else self.n
         dev = self.device
+        # outputs live in buffers owned by the queue (valid until the next step): a steady step is two ~10 us
+        # launches, three torch.empty calls would cost as much again on the host
+        ob = self._out
+        if ob is None or ob[0].numel() < N:
+            cap = max(N, 2 * (ob[0].numel() if ob else 0))
+            ob = self._out = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
+                              torch.empty(cap, dtype=torch.uint8, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
         if perm_out is None:
-            perm_out = torch.empty(N, dtype=torch.int32, device=dev)
-        n_sel = torch.empty(1, dtype=torch.int32, device=dev)
-        ran = torch.empty(N, dtype=torch.uint8, device=dev) if want_ran else None
-        granted = torch.empty(N, dtype=torch.int32, device=dev) if want_granted else None
+            perm_out = ob[0][:N]
+        n_sel = ob[1]
+        ran = ob[2][:N] if want_ran else None
+        granted = ob[3][:N] if want_granted else None
         buf = self.ws.get(N)
-        with torch.cuda.device(dev):
-            _lib.check(self.ws.lib.ltr_queue_step(s.data_ptr(), p.data_ptr(), i.data_ptr(), r.data_ptr(), None,
-                                                  _p(members), N, self.starv, self.period,
-                                                  _flags(self.starv, False, None), new_tokens.data_ptr(),
-                                                  new_seqs.data_ptr(), _p(chunkable), int(token_budget),
-                                                  int(max_num_seqs), perm_out.data_ptr(), n_sel.data_ptr(), _p(ran),
-                                                  _p(granted), buf.data_ptr(), buf.numel(), _stream(dev)),
-                       "ltr_queue_step")
+        if torch.cuda.current_device() != dev.index:
+            torch.cuda.set_device(dev)               # (bench / scheduler loops run on one device: normally a no-op)
+        _lib.check(self.ws.lib.ltr_queue_step(s.data_ptr(), p.data_ptr(), i.data_ptr(), r.data_ptr(), None,
+                                              _p(members), N, self.starv, self.period,
+                                              _flags(self.starv, False, None), new_tokens.data_ptr(),
+                                              new_seqs.data_ptr(), _p(chunkable), int(token_budget),
+                                              int(max_num_seqs), perm_out.data_ptr(), n_sel.data_ptr(), _p(ran),
+                                              _p(granted), buf.data_ptr(), buf.numel(), _stream(dev)),
+                   "ltr_queue_step")
         return perm_out, n_sel, ran, granted
