@@ -144,6 +144,27 @@ __device__ __forceinline__ int lds_off_h(int row, int kc) {   // in halves
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+// 16-byte epilogue store.  The outputs of a launch (1.4 GB) are read back by the NEXT launch, long after they have left
+// the 4 MiB L2 of the XCD, while the operand panels the co-resident tiles share live there: the stores are issued
+// non-temporal so that they claim as little of it as possible.  LTR_EPI_STORE selects the cache policy (A/B knob,
+// profiles/r02_ab_gemm_probes.txt): 0 plain 235.0 / 236.9 ms per call, 1 nt 231.8 (kept), 2 sc1 233.8, 3 sc0 sc1 235.1
+#ifndef LTR_EPI_STORE
+#define LTR_EPI_STORE 1
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void epi_store16(void* p, const void* v) {
+  const u32x4 d = *reinterpret_cast<const u32x4*>(v);
+#if LTR_EPI_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+#elif LTR_EPI_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+#elif LTR_EPI_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+#else
+  *reinterpret_cast<u32x4*>(p) = d;
+#endif
+}
+
 #ifdef LTR_GEMM_TIMELINE
 __device__ unsigned long long g_timeline[8192 * 4];
 __device__ unsigned long long g_waits[8192 * 2];
@@ -197,6 +218,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   auto issue = [&](int stage, int k0) {
     __half* base = smem + stage * STAGE;
     const size_t ka = (size_t)(k0 / BK16) * a_slab, kw = (size_t)(k0 / BK16) * w_slab;
+    // (default cache policy on purpose: the non-temporal hint on the activation stream costs 5 % of the call for the
+    // narrow GEMMs alone and 11 % for all - the co-resident tiles share these lines through the L2)
     __builtin_amdgcn_global_load_lds((gbl_void*)(ga + ka), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
 #pragma unroll
@@ -366,8 +389,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         x[0] += ra[it].x; x[1] += ra[it].y; x[2] += ra[it].z; x[3] += ra[it].w;
         x[4] += rb[it].x; x[5] += rb[it].y; x[6] += rb[it].z; x[7] += rb[it].w;
         if (ep.out_f32) {
-          *reinterpret_cast<float4*>(ep.out_f32 + o[it]) = make_float4(x[0], x[1], x[2], x[3]);
-          *reinterpret_cast<float4*>(ep.out_f32 + o[it] + (ecol_b - ecol)) = make_float4(x[4], x[5], x[6], x[7]);
+          epi_store16(ep.out_f32 + o[it], x);
+          epi_store16(ep.out_f32 + o[it] + (ecol_b - ecol), x + 4);
         }
         if (ep.out_hi) {
           __half h[8], l[8];
@@ -378,8 +401,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
           if (h[0] == __half(12345.f) && l[7] == __half(54321.f))
 #endif
           {
-            *reinterpret_cast<uint4*>((__half*)ep.out_hi + os) = *reinterpret_cast<const uint4*>(h);
-            *reinterpret_cast<uint4*>((__half*)ep.out_lo + os) = *reinterpret_cast<const uint4*>(l);
+            epi_store16((__half*)ep.out_hi + os, h);
+            epi_store16((__half*)ep.out_lo + os, l);
           }
         }
         if (LNM == LNP) {
@@ -403,8 +426,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
           const uint4 lv = odd ? make_uint4(lr.x, lr.y, lk.x, lk.y) : make_uint4(lk.x, lk.y, lr.x, lr.y);
           const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
           const size_t oo = slab_off(gr[it], c0, M);
-          *reinterpret_cast<uint4*>((__half*)ep.ln_hi + oo) = hv;
-          *reinterpret_cast<uint4*>((__half*)ep.ln_lo + oo) = lv;
+          epi_store16((__half*)ep.ln_hi + oo, &hv);
+          epi_store16((__half*)ep.ln_lo + oo, &lv);
           // (mean, M2) of this wave's 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
           // row, so they are active exactly when this lane is)
           float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
