@@ -292,7 +292,6 @@ class MI355XRanker:
         out = list(operator.itemgetter(*perm)(reqs)) if n > 1 else [reqs[perm[0]]]
         if self.mirror_host and policy == "opt" and q.starv != -1:
             self.sync_host(reqs)
-        self._gc_slots(n)
         self.stats["rank_calls"] += 1
         self.stats["rank_seconds"] += time.perf_counter() - t0
         return out
@@ -336,7 +335,9 @@ class MI355XRanker:
             if timed:
                 print("OPT-TIME: ", time.time() - t0)
         reqs = list(waiting) + list(scheduler.running) + list(scheduler.swapped)
-        return self.order(reqs, policy)
+        out = self.order(reqs, policy)
+        self._gc_slots(len(reqs))        # `reqs` is every live request here (not so for direct order() calls on a subset)
+        return out
 
     # ---- aging loop of _general_schedule ----------------------------------------------------
     def age(self, all_pri: Sequence, running_this_step: Iterable) -> None:

@@ -259,13 +259,18 @@ class DeviceQueue:
         ran = ob[2][:N] if want_ran else None
         granted = ob[3][:N] if want_granted else None
         buf = self.ws.get(N)
-        if torch.cuda.current_device() != dev.index:
-            torch.cuda.set_device(dev)               # (bench / scheduler loops run on one device: normally a no-op)
-        _lib.check(self.ws.lib.ltr_queue_step(s.data_ptr(), p.data_ptr(), i.data_ptr(), r.data_ptr(), None,
-                                              _p(members), N, self.starv, self.period,
-                                              _flags(self.starv, False, None), new_tokens.data_ptr(),
-                                              new_seqs.data_ptr(), _p(chunkable), int(token_budget),
-                                              int(max_num_seqs), perm_out.data_ptr(), n_sel.data_ptr(), _p(ran),
-                                              _p(granted), buf.data_ptr(), buf.numel(), _stream(dev)),
-                   "ltr_queue_step")
+
+        def call():
+            _lib.check(self.ws.lib.ltr_queue_step(s.data_ptr(), p.data_ptr(), i.data_ptr(), r.data_ptr(), None,
+                                                  _p(members), N, self.starv, self.period,
+                                                  _flags(self.starv, False, None), new_tokens.data_ptr(),
+                                                  new_seqs.data_ptr(), _p(chunkable), int(token_budget),
+                                                  int(max_num_seqs), perm_out.data_ptr(), n_sel.data_ptr(), _p(ran),
+                                                  _p(granted), buf.data_ptr(), buf.numel(), _stream(dev)),
+                       "ltr_queue_step")
+        if torch.cuda.current_device() == dev.index:     # the usual case: skip the context manager (a few us per step)
+            call()
+        else:
+            with torch.cuda.device(dev):
+                call()
         return perm_out, n_sel, ran, granted
