@@ -90,7 +90,9 @@ def test_config2_opt125m_8k_queue_full_size():
     h = torch.from_numpy(sc.hidden(ids[t0:t1], cu_p, n_layers=-1)).to(dev)
     full = torch.empty(r1 - r0, device=dev)
     sc.pool_head_device(h, torch.from_numpy(cu_p).to(dev), r1 - r0, full)
-    assert np.array_equal(full.cpu().numpy(), s4[r0:r1])
+    d_prune = float(np.abs(full.cpu().numpy() - s4[r0:r1]).max())   # last query: f32 VALU attention vs split-fp16 MFMA
+    print(f"config 2: pruned last layer vs full forward of pass 2, max|d| = {d_prune:.3e}")
+    assert d_prune <= 5e-6
     del h
     # the oracle on requests from every pass, pass boundaries included
     sample = _sample(passes, 8192, 28, seed=1)

@@ -120,19 +120,25 @@ def test_pool_head_kernel_alone(dev, mk, mode):
 
 
 @pytest.mark.parametrize("mk", [OPTSpec.tiny_pre_ln, OPTSpec.tiny_post_ln])
-def test_last_layer_pruning_is_invisible(dev, mk):
-    """ltr_score carries only the last-token rows through the tail of the last layer;
-    ltr_forward_hidden runs every row.  Pooling the full hidden states must give the same
-    scores bit for bit (out_proj / LayerNorm / MLP are per-token maps)."""
+def test_last_layer_pruning_is_invisible(dev, mk, monkeypatch):
+    """ltr_score carries only the last-token rows through the last layer: Q, the attention output, out_proj, the
+    LayerNorms and the MLP for n_req rows, K | V for every token; ltr_forward_hidden runs every row.  With the
+    last-query attention switched off (LTR_NO_LASTQ=1) only per-token maps are pruned and pooling the full hidden
+    states gives the same scores bit for bit; with it (default) the last query's softmax runs in f32 on the VALU
+    instead of the split-fp16 MFMA passes - f32-grade agreement."""
     spec = mk()
     ckpt = seeded_checkpoint(spec, 6)
-    ids, cu = synthetic_batch(spec, [9, 1, 64, 65, 2, 130, 33, 128, 31], 10)
+    ids, cu = synthetic_batch(spec, [9, 1, 64, 65, 2, 130, 33, 128, 31, 7, 8, 150], 10)
     sc = _scorer(spec, ckpt, dev, "f16")
     pruned = sc.score(ids, cu)
     h = torch.from_numpy(sc.hidden(ids, cu, n_layers=-1)).to(dev)
     full = torch.empty(len(cu) - 1, device=dev)
     sc.pool_head_device(h, torch.from_numpy(cu).to(dev), len(cu) - 1, full)
-    assert np.array_equal(pruned, full.cpu().numpy())
+    full = full.cpu().numpy()
+    np.testing.assert_allclose(pruned, full, atol=2e-6, rtol=0)
+    monkeypatch.setenv("LTR_NO_LASTQ", "1")
+    sc2 = _scorer(spec, ckpt, dev, "f16")
+    assert np.array_equal(sc2.score(ids, cu), full)
 
 
 def test_chunking_is_invisible(dev):
@@ -523,4 +529,5 @@ def test_layernorm_fold_on_and_off_agree(dev, monkeypatch):
     assert ea <= 2e-5 and eb <= 2e-5
     folded.profile(True); folded.profile_read(True); folded.score(ids, cu)
     plain.profile(True); plain.profile_read(True); plain.score(ids, cu)
-    assert folded.profile_read()["ln"]["launches"] == 1 and plain.profile_read()["ln"]["launches"] == 2 * spec.num_hidden_layers
+    # + 1: the LayerNorm of the n_req last-token rows in front of the last layer's Q GEMM (last-query pruning)
+    assert folded.profile_read()["ln"]["launches"] == 2 and plain.profile_read()["ln"]["launches"] == 2 * spec.num_hidden_layers + 1

@@ -56,6 +56,11 @@ struct ltr_model {
   bool ln_fold = false;
   float* fold = nullptr;
   std::vector<const float*> fold_c_qkv, fold_d_qkv, fold_c_fc1, fold_d_fc1;
+  // F16 mode: the LAST layer's qkv_proj as two images, q rows [0, H) and k | v rows [H, 3H) - a scoring call needs
+  // that layer's Q for the last token of each request only (forward_chunk; LTR_NO_LASTQ=1 switches it off)
+  bool lastq = false;
+  const void* last_q_w = nullptr;
+  const void* last_kv_w = nullptr;
   ~ltr_model() {
     if (packed) (void)hipFree(packed);
     if (fold) (void)hipFree(fold);
@@ -213,21 +218,63 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       rc = lnorm(Tc, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ws.a);
       if (rc) return rc;
     }
-    {
-      GemmArgs g{};
-      g.a = ws.a; g.w = m->gemm_lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
-      if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
-      g.M = Tc; g.N = 3 * H; g.K = H; g.a_slab = wd == LTR_W_F16;   // A from LayerNorm / to_operand / the fold
-      if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L]; g.bias = m->fold_d_qkv[L]; g.ln_parts = H / 64; }
-      if ((rc = gemm(g))) return rc;
+    const bool last_pruned = prune_last && L == nl - 1;
+    // F16 mode, last layer of a scoring call: Q and the attention output are needed for the last token of each
+    // request only; K and V for every token.
+    const bool lastq = last_pruned && m->lastq && L == d.num_layers - 1;
+    if (lastq) {
+      const float* qkv_b = (const float*)m->lw(L, LTR_WL_QKV_B);
+      // K | V of every token: hi|lo planes [Tc, 2H] at the head of the qkv region
+      AOp kv{ws.qkv.hi, (char*)ws.qkv.hi + (size_t)Tc * 2 * H * 2};
+      {
+        GemmArgs g{};
+        g.a = ws.a; g.w = m->last_kv_w; g.bias = qkv_b + H; g.out_split = kv;
+        g.M = Tc; g.N = 2 * H; g.K = H; g.a_slab = 1;
+        if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L] + H; g.bias = m->fold_d_qkv[L] + H; g.ln_parts = H / 64; }
+        if ((rc = gemm(g))) return rc;
+      }
+      // The nreq last-token rows of the residual stream go to the tail of the qkv region (Tc * H * 4 bytes are
+      // free behind the K | V planes); their LayerNorm (pre-LN; computed directly, the folded operand of the
+      // whole pass is not compacted) or their split copy (post-LN) is the operand of the Q GEMM.  ws.a is dead
+      // once the K | V GEMM has read it: it holds the Q operand, then the attention output; ws.h is dead once the
+      // rows are gathered: it holds q.
+      hb = (float*)((char*)ws.qkv.hi + (size_t)Tc * 2 * H * 4);
+      ab = AOp{ws.a.hi, (char*)ws.a.hi + (size_t)nreq * H * 2};
+      fb = AOp{ws.f.hi, (char*)ws.f.hi + (size_t)nreq * F * 2};
+      Mr = nreq;
+      if ((rc = launch_gather_last_rows(wd, cu_dev + r0, t0, nreq, H, ws.h, AOp{nullptr, nullptr}, hb, AOp{nullptr, nullptr}, s)))
+        return rc;
+      if (d.pre_ln) rc = lnorm(nreq, hb, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ab);
+      else rc = launch_to_operand(wd, hb, nreq, H, ab, s);
+      if (rc) return rc;
+      float* qf = ws.h;
+      {
+        GemmArgs g{};
+        g.a = ab; g.w = m->last_q_w; g.bias = qkv_b; g.out_f32 = qf; g.M = nreq; g.N = H; g.K = H; g.a_slab = 1;
+        if ((rc = gemm(g))) return rc;
+      }
+      {
+        ProfScope p(m, LTR_K_ATTN, 4.0 * Tc * H, s);
+        rc = launch_attention_lastq(qf, kv, cu_dev + r0, nreq, H, d.num_heads, ab, s);
+      }
+      if (rc) return rc;
+    } else {
+      {
+        GemmArgs g{};
+        g.a = ws.a; g.w = m->gemm_lw(L, LTR_WL_QKV_W); g.bias = (const float*)m->lw(L, LTR_WL_QKV_B);
+        if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
+        g.M = Tc; g.N = 3 * H; g.K = H; g.a_slab = wd == LTR_W_F16;   // A from LayerNorm / to_operand / the fold
+        if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L]; g.bias = m->fold_d_qkv[L]; g.ln_parts = H / 64; }
+        if ((rc = gemm(g))) return rc;
+      }
+      {
+        ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
+        rc = launch_attention(m->dbg_attn_valu && wd == LTR_W_F16 ? -1 : wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads,
+                              ws.blk, ws.a, L == 0, s);
+      }
+      if (rc) return rc;
     }
-    {
-      ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
-      rc = launch_attention(m->dbg_attn_valu && wd == LTR_W_F16 ? -1 : wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads,
-                            ws.blk, ws.a, L == 0, s);
-    }
-    if (rc) return rc;
-    if (prune_last && L == nl - 1) {
+    if (last_pruned && !lastq) {
       // Only the last token of each prompt is scored (logits_processor.py:74-79), and after the
       // attention of the LAST layer no token reads another token's state: out_proj, the LayerNorms
       // and the MLP are per-token maps.  Compact the nreq last-token rows of h and of the attention
@@ -384,7 +431,9 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
       items.push_back({b + LTR_WL_FC1_W, F, H});
       items.push_back({b + LTR_WL_FC2_W, H, F});
     }
-    size_t total = 0;
+    { const char* e = getenv("LTR_NO_LASTQ"); m->lastq = desc->num_layers > 0 && !m->dbg_attn_valu && !(e && e[0] == '1'); }
+    const size_t last_bytes = m->lastq ? 3 * H * H * 2 : 0;   // H * H and 2H * H halves: both multiples of 256 B
+    size_t total = last_bytes;
     for (auto& it : items) total += (it.n * it.k * 2 + 255) / 256 * 256;
     if (total) {
       if (hipMalloc(&m->packed, total) != hipSuccess) {
@@ -398,6 +447,14 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
         if ((rc = launch_pack_weight(m->w[it.idx], dst, (int)it.n, (int)it.k, cs))) { delete m; return rc; }
         m->wg[it.idx] = dst;
         off += (it.n * it.k * 2 + 255) / 256 * 256;
+      }
+      if (m->lastq) {   // nn.Linear layout [3H, H] row-major: q | k | v row blocks (opt.py:411-417)
+        const char* src = (const char*)m->lw(desc->num_layers - 1, LTR_WL_QKV_W);
+        char* dq = (char*)m->packed + off;
+        char* dkv = dq + H * H * 2;
+        if ((rc = launch_pack_weight(src, dq, (int)H, (int)H, cs)) ||
+            (rc = launch_pack_weight(src + H * H * 2, dkv, (int)(2 * H), (int)H, cs))) { delete m; return rc; }
+        m->last_q_w = dq; m->last_kv_w = dkv;
       }
     }
   }

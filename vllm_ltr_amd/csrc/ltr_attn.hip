@@ -405,6 +405,122 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   }
 }
 
+
+// Last layer of a scoring call: only the LAST token of each prompt is pooled (logits_processor.py:74-79), so of
+// the last layer's attention only the last query of every request is needed - it reads all the request's keys
+// and values (the K | V GEMM still runs over every token), but Q, the softmax and the output exist for n_req rows
+// instead of T.  That is a matrix-vector problem per (request, head): ~4 B of K/V per 2 FLOP, HBM-bound, so it
+// runs on the VALU in f32 straight from the hi|lo planes (k = hi + lo is exact in f32).
+// Workgroup = (request, head), 4 waves; a wave instruction covers 8 keys x 64 dims (lane = key j8 x 16-byte
+// piece c), groups of 8 keys are dealt round-robin to the waves, every lane runs its own online softmax over
+// "its" keys for "its" 8 dims, and the (m, l, o) states are merged at the end (lanes, then waves through LDS).
+constexpr int LQ_WAVES = 4;
+__global__ void __launch_bounds__(LQ_WAVES * 64) attn_lastq_kernel(const float* __restrict__ q /*[n_req, H]*/,
+                                                                   const __half* __restrict__ kv_hi,
+                                                                   const __half* __restrict__ kv_lo /*[T, 2H]: k | v*/,
+                                                                   const int32_t* __restrict__ cu, int H,
+                                                                   float scale_log2e, __half* __restrict__ out_hi,
+                                                                   __half* __restrict__ out_lo /*[n_req, H]*/) {
+  __shared__ float s_o[LQ_WAVES][D];
+  __shared__ float s_ml[LQ_WAVES][2];
+  const int req = blockIdx.x, head = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 7, j8 = lane >> 3;
+  const int c0 = cu[req], L = cu[req + 1] - c0;
+  if (L <= 0) return;
+  const size_t ld = (size_t)2 * H;
+  const size_t base = (size_t)(c0 - cu[0]) * ld + head * D + c * 8;
+  float qv[8];
+  {
+    const float* qp = q + (size_t)req * H + head * D + c * 8;
+    const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+    qv[0] = a.x * scale_log2e; qv[1] = a.y * scale_log2e; qv[2] = a.z * scale_log2e; qv[3] = a.w * scale_log2e;
+    qv[4] = b.x * scale_log2e; qv[5] = b.y * scale_log2e; qv[6] = b.z * scale_log2e; qv[7] = b.w * scale_log2e;
+  }
+  float m = NEG, l = 0.f, o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = 0.f;
+  const int ngroups = (L + 7) >> 3;
+  auto widen = [](const uint4& hi, const uint4& lo, float* x) {
+    const __half2* h2 = reinterpret_cast<const __half2*>(&hi);
+    const __half2* l2 = reinterpret_cast<const __half2*>(&lo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float2 a = __half22float2(h2[i]), b = __half22float2(l2[i]);
+      x[2 * i] = a.x + b.x; x[2 * i + 1] = a.y + b.y;
+    }
+  };
+  auto step = [&](bool valid, const uint4& kh, const uint4& kl, const uint4& vh, const uint4& vl) {
+    float k[8], v[8];
+    widen(kh, kl, k);
+    widen(vh, vl, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = fmaf(qv[i], k[i], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (!valid) return;
+    const float mn = fmaxf(m, s);
+    const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+    l = l * alpha + p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = fmaf(p, v[i], o[i] * alpha);
+    m = mn;
+  };
+  // two groups of 8 keys per iteration: eight 16-byte loads in flight per lane
+  for (int g = wave; g < ngroups; g += 2 * LQ_WAVES) {
+    const int ja = g * 8 + j8, jb = (g + LQ_WAVES) * 8 + j8;
+    const bool va = ja < L, vb = jb < L;
+    const size_t oa = base + (size_t)(va ? ja : 0) * ld, ob = base + (size_t)(vb ? jb : 0) * ld;
+    const uint4 kha = *reinterpret_cast<const uint4*>(kv_hi + oa), kla = *reinterpret_cast<const uint4*>(kv_lo + oa);
+    const uint4 vha = *reinterpret_cast<const uint4*>(kv_hi + oa + H), vla = *reinterpret_cast<const uint4*>(kv_lo + oa + H);
+    const uint4 khb = *reinterpret_cast<const uint4*>(kv_hi + ob), klb = *reinterpret_cast<const uint4*>(kv_lo + ob);
+    const uint4 vhb = *reinterpret_cast<const uint4*>(kv_hi + ob + H), vlb = *reinterpret_cast<const uint4*>(kv_lo + ob + H);
+    step(va, kha, kla, vha, vla);
+    step(vb, khb, klb, vhb, vlb);
+  }
+  // merge the 8 key lanes of the wave (lanes that differ in j8 hold the same dims)
+#pragma unroll
+  for (int x = 8; x < 64; x <<= 1) {
+    const float m2 = __shfl_xor(m, x, 64), l2 = __shfl_xor(l, x, 64);
+    const float mn = fmaxf(m, m2);
+    const float a = exp2f(m - mn), b = exp2f(m2 - mn);
+    l = l * a + l2 * b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = o[i] * a + __shfl_xor(o[i], x, 64) * b;
+    m = mn;
+  }
+  if (j8 == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_o[wave][c * 8 + i] = o[i];
+    if (c == 0) { s_ml[wave][0] = m; s_ml[wave][1] = l; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float mt = NEG;
+#pragma unroll
+    for (int w = 0; w < LQ_WAVES; ++w) mt = fmaxf(mt, s_ml[w][0]);
+    float lt = 0.f, ot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ot[i] = 0.f;
+#pragma unroll
+    for (int w = 0; w < LQ_WAVES; ++w) {
+      const float a = exp2f(s_ml[w][0] - mt);
+      lt += s_ml[w][1] * a;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ot[i] += s_o[w][c * 8 + i] * a;
+    }
+    const float inv = 1.0f / lt;
+    __half hh[8], ll[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split_f16(ot[i] * inv, hh[i], ll[i]);
+    const size_t ob = (size_t)req * H + head * D + c * 8;
+    *reinterpret_cast<uint4*>(out_hi + ob) = *reinterpret_cast<const uint4*>(hh);
+    *reinterpret_cast<uint4*>(out_lo + ob) = *reinterpret_cast<const uint4*>(ll);
+  }
+}
+
 }  // namespace
 
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
@@ -436,6 +552,17 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
       attn_f32_kernel<true><<<grid, 64, 0, s>>>((const float*)qkv.hi, cu, blk_start, blk_desc, n_req, H, scale_log2e,
                                                 out.hi, out.lo, nullptr);
   }
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+int launch_attention_lastq(const float* q, AOp kv, const int32_t* cu, int n_req, int H, int n_heads, AOp out,
+                           hipStream_t s) {
+  if (n_req == 0) return LTR_OK;
+  if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
+  const float scale_log2e = 0.125f * 1.4426950408889634f;
+  attn_lastq_kernel<<<dim3(n_req, n_heads), LQ_WAVES * 64, 0, s>>>(q, (const __half*)kv.hi, (const __half*)kv.lo, cu, H,
+                                                                   scale_log2e, (__half*)out.hi, (__half*)out.lo);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }

@@ -82,7 +82,8 @@ int launch_ln_fold_coeff(const void* w_f16, const float* gamma, const float* bet
 int launch_layernorm(int wdtype, const float* x, const float* gamma, const float* beta, int M, int H,
                      float* out_f32 /*nullable, may alias x*/, AOp out_op /*nullable*/, hipStream_t s);
 int launch_to_operand(int wdtype, const float* x, int M, int H, AOp out, hipStream_t s);
-// compact the last-token rows (cu[i+1]-1-tok_off) of the f32 stream and of an operand buffer to [n_req, H]
+// compact the last-token rows (cu[i+1]-1-tok_off) of the f32 stream and of an operand buffer (a_src.hi may be
+// null: the f32 rows only) to [n_req, H]
 int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_req, int H, const float* h_src, AOp a_src,
                             float* h_dst, AOp a_dst, hipStream_t s);
 
@@ -96,6 +97,11 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]
                      int T, int H, int n_heads, int32_t* blk_start /*scratch: (n_req+4)*4 + (T/64+n_req+1)*16 bytes*/, AOp out,
                      int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s,
                      float* lse2 = nullptr /*F32 mode: [T, heads] log2-domain log-sum-exp of every query row (training)*/);
+
+// F16 mode, last layer of a scoring call: attention of the LAST query of every request only.  q f32 [n_req, H]
+// (unscaled), kv = hi|lo planes [T, 2H] (k | v), out = row-major hi|lo planes [n_req, H]
+int launch_attention_lastq(const float* q, AOp kv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req, int H,
+                           int n_heads, AOp out, hipStream_t s);
 
 int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu /*nullptr: rows are already compact*/, int tok_off,
                      int N, int H, int De,

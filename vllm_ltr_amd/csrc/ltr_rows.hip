@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256) gather_last_rows_kernel(const int32_t* __
     float v[8];
     Vec8<float>::load(h_src + srow * H + c, v);
     store8_f32(h_dst + drow * H + c, v);
+    if (!a_src) continue;
     if (SPLIT) {   // fp16 hi | lo planes: 16 B per plane
       const __half* sh = reinterpret_cast<const __half*>(a_src);
       __half* dh = reinterpret_cast<__half*>(a_dst);
@@ -273,7 +274,8 @@ int launch_gather_last_rows(int wdtype, const int32_t* cu, int tok_off, int n_re
   if (n_req == 0) return LTR_OK;
   dim3 grid((n_req + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   if (wdtype == LTR_W_F16) {
-    const int64_t ps = ((const __half*)a_src.lo - (const __half*)a_src.hi), pd = ((__half*)a_dst.lo - (__half*)a_dst.hi);
+    const int64_t ps = a_src.hi ? ((const __half*)a_src.lo - (const __half*)a_src.hi) : 0;
+    const int64_t pd = a_src.hi ? ((__half*)a_dst.lo - (__half*)a_dst.hi) : 0;
     gather_last_rows_kernel<true><<<grid, 256, 0, s>>>(cu, tok_off, n_req, H, ps, pd, h_src, (const char*)a_src.hi, h_dst,
                                                        (char*)a_dst.hi);
   } else {
