@@ -155,11 +155,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void epi_store16(void* p, const void* v) {
   const u32x4 d = *reinterpret_cast<const u32x4*>(v);
 #if LTR_EPI_STORE == 1
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+  // Inline asm (the compiler's own __builtin_nontemporal_store costs out_proj 12 %: 610 vs 545 us per 196k-token launch,
+  // diag/gemm_bench.hip) behind 16 wait states: the hazard recogniser does not look inside asm statements, and in an
+  // experimental epilogue a global_store placed right behind the VALU / LDS-permute ops that built its operands
+  // stored stale registers in one lane of 16 (diag/gemm_check.hip); the s_nops cured it and cost nothing measurable.
+  asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+  asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+  asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+#elif LTR_EPI_STORE == 5
+  __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(p));
 #else
   *reinterpret_cast<u32x4*>(p) = d;
 #endif
