@@ -327,6 +327,12 @@ def main():
                          "traffic": traffic,
                          "launches_per_step": gemm["launches"] // max(args.steps, 1),
                          "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
+                         # the same kernel against the OTHER roof: PMC bytes per launch / live launch time, over 8 TB/s.
+                         # The split-fp16 design moves 4 B per activation element between launches, so the MFMA-bound
+                         # kernel is also a heavy HBM client (DESIGN.md 4.1 "bytes")
+                         "hbm_gbs": (traffic / (gemm["ms"] / max(gemm["launches"], 1) * 1e-3) / 1e9) if traffic else None,
+                         "hbm_frac": (traffic / (gemm["ms"] / max(gemm["launches"], 1) * 1e-3) / (PEAK_HBM_GBS * 1e9))
+                         if traffic else None,
                          "note": "the GEMM launches also carry the LayerNorm work of the layer (LayerNorm fold: operand + row "
                                  "statistics in the producer epilogue, normalisation in the consumer epilogue); "
                                  "`unfused` = the same forward with separate LayerNorm launches (LTR_NO_LN_FOLD=1)",
