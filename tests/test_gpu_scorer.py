@@ -168,6 +168,16 @@ def test_edge_inputs(dev):
     L = spec.max_position_embeddings                                                # maximum length
     ids, cu = synthetic_batch(spec, [L, 1, L], 2)
     assert np.abs(sc.score(ids, cu) - orc.score(ids, cu)).max() <= TOL
+    # only one-token requests: n_req == T, the compact last-token buffers of the last layer are as large as the pass
+    for mk in (OPTSpec.tiny_pre_ln, OPTSpec.tiny_post_ln):
+        sp2 = mk()
+        ck2 = seeded_checkpoint(sp2, 9)
+        ids1, cu1 = synthetic_batch(sp2, [1] * 300, 4)
+        s2 = _scorer(sp2, ck2, dev, "f16")
+        want = OracleOPTScorer(sp2, ck2).score(ids1, cu1)
+        assert np.abs(s2.score(ids1, cu1) - want).max() <= TOL
+        s2.set_chunk_tokens(64)                                                      # ... and across several passes
+        assert np.abs(s2.score(ids1, cu1) - want).max() <= TOL
     with pytest.raises(LtrError):                                                   # over-long prompt
         i2, c2 = synthetic_batch(spec, [L + 1], 3)
         sc.score(i2, c2)
