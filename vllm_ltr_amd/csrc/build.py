@@ -55,7 +55,27 @@ def build(force: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    _build_tools(force)
     return LIB
+
+
+# element-level checker of the GEMM's LayerNorm-fold epilogues (diag/gemm_check.hip), run by the -m gpu tests
+TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip")}
+
+
+def _build_tools(force: bool) -> None:
+    out_dir = os.path.join(HERE, "build")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, src in TOOLS.items():
+        exe = os.path.join(out_dir, name)
+        deps = [os.path.join(HERE, src), LIB] + [os.path.join(HERE, h) for h in HEADERS]
+        if force or _stale(exe, deps):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-I" + HERE,
+                   "-I" + os.path.join(HERE, "..", "..", "include"), os.path.join(HERE, src), "-L" + HERE, "-lltr_hip",
+                   "-Wl,-rpath,$ORIGIN/..", "-o", exe]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
 
 
 if __name__ == "__main__":

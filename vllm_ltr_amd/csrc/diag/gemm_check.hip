@@ -1,6 +1,7 @@
 // Diagnostic: the F16 GEMM's LayerNorm-fold producer (LNP) and consumer (LNC) epilogues against a host
 // computation, element by element (links libltr_hip.so, calls ltr::launch_gemm directly).
-//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I.. -I../../../include diag/gemm_check.hip -L. -lltr_hip -Wl,-rpath,$PWD -o /tmp/gemm_check
+// Built by vllm_ltr_amd/csrc/build.py into csrc/build/gemm_check and run by tests/test_gpu_gemm_epilogue.py
+// (NaN-safe comparisons: a stale-register store can leave NaN bit patterns behind).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,11 +49,11 @@ int main(int argc, char** argv) {
       for (int k = 0; k < K; ++k) s += ((double)__half2float(ahi[(size_t)m * K + k]) + (double)__half2float(alo[(size_t)m * K + k])) * (double)__half2float(w[(size_t)n * K + k]);
       s += bias[n] + resid[(size_t)m * N + n];
       ref[(size_t)m * N + n] = s;
-      if (fabs(out[(size_t)m * N + n] - s) > 1e-4) { if (bad_out++ < 5) printf("out[%d,%d] = %g want %g\n", m, n, out[(size_t)m * N + n], s); }
+      if (!(fabs(out[(size_t)m * N + n] - s) <= 1e-4)) { if (bad_out++ < 5) printf("out[%d,%d] = %g want %g\n", m, n, out[(size_t)m * N + n], s); }
       const size_t so = ((size_t)(n >> 5) * M + m) * 32 + (n & 31);
       const double got = (double)__half2float(ln[so]) + (double)__half2float(ln[(size_t)M * N + so]);
       const double want = s * gamma[n] * 16.0;
-      if (fabs(got - want) > 1e-3 * (1 + fabs(want))) { if (bad_ln++ < 12 || (bad_ln % 97) == 0) printf("a'[%d,%d] = %g (hi %g lo %g) want %g\n", m, n, got, __half2float(ln[so]), __half2float(ln[(size_t)M * N + so]), want); }
+      if (!(fabs(got - want) <= 1e-3 * (1 + fabs(want)))) { if (bad_ln++ < 12 || (bad_ln % 97) == 0) printf("a'[%d,%d] = %g (hi %g lo %g) want %g\n", m, n, got, __half2float(ln[so]), __half2float(ln[(size_t)M * N + so]), want); }
     }
     for (int p = 0; p < N / 64; ++p) {
       double mu = 0, q = 0;
@@ -60,7 +61,7 @@ int main(int argc, char** argv) {
       mu /= 64;
       for (int c = 0; c < 64; ++c) { double d = ref[(size_t)m * N + p * 64 + c] - mu; q += d * d; }
       const float2 s2 = st[(size_t)p * M + m];
-      if (fabs(s2.x - mu) > 1e-4 || fabs(s2.y - q) > 1e-3 * (1 + q)) { if (bad_st++ < 12) printf("stats[piece %d, row %d] = (%g, %g) want (%g, %g)\n", p, m, s2.x, s2.y, mu, q); }
+      if (!(fabs(s2.x - mu) <= 1e-4) || !(fabs(s2.y - q) <= 1e-3 * (1 + q))) { if (bad_st++ < 12) printf("stats[piece %d, row %d] = (%g, %g) want (%g, %g)\n", p, m, s2.x, s2.y, mu, q); }
     }
   }
   printf("LNP: bad out %d, bad a' %d, bad stats %d\n", bad_out, bad_ln, bad_st);
@@ -96,9 +97,9 @@ int main(int argc, char** argv) {
       double s = b2[n2];
       for (int n = 0; n < N; ++n) s += ((ref[(size_t)m * N + n] - mu) * rstd * gamma[n] + beta[n]) * (double)__half2float(w2[(size_t)n2 * N + n]);
       const double got = (double)__half2float(o2[(size_t)m * N2 + n2]) + (double)__half2float(o2[(size_t)M * N2 + (size_t)m * N2 + n2]);
-      if (fabs(got - s) > 1e-3 * (1 + fabs(s))) { if (bad_c++ < 12) printf("lnc[%d,%d] = %g want %g\n", m, n2, got, s); }
+      if (!(fabs(got - s) <= 1e-3 * (1 + fabs(s)))) { if (bad_c++ < 12) printf("lnc[%d,%d] = %g want %g\n", m, n2, got, s); }
     }
   }
   printf("LNC: bad %d of %d\n", bad_c, M * N2);
-  return 0;
+  return (bad_out || bad_ln || bad_st || bad_c) ? 1 : 0;
 }
