@@ -32,7 +32,8 @@ enum {
   LTR_E_INVAL = -22,   /* bad argument / unsupported shape                  */
   LTR_E_NOMEM = -12,   /* workspace too small                               */
   LTR_E_HIP = -5,      /* a HIP runtime call failed (see ltr_last_error)    */
-  LTR_E_NODEV = -19    /* no gfx950 device                                  */
+  LTR_E_NODEV = -19,   /* no gfx950 device                                  */
+  LTR_E_RANGE = -34    /* an activation left the fp16 range of the split path (ltr_status) */
 };
 
 /* weight element type of matrices and embedding tables */
@@ -141,7 +142,11 @@ int ltr_score(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
  * reported by the call that meets it: the embedding kernel flags it (and reads row 0 / the last
  * row instead of faulting; the scores of that call are then meaningless).  ltr_status
  * synchronises `stream`, returns LTR_E_INVAL if any forward since the previous ltr_status saw
- * such an id (LTR_OK otherwise) and clears the flag.  Call it wherever the scores are read. */
+ * such an id (LTR_OK otherwise) and clears the flag.  Call it wherever the scores are read.
+ * LTR_E_RANGE: the residual stream of an F16-mode pre-LN model exceeded what the LayerNorm-fold
+ * operand can carry in fp16 (|x * gamma| > 4094; the reference's own fp16 GPU path overflows at
+ * |x| > 65504): the scores of that call are invalid; a handle created with LTR_NO_LN_FOLD=1 in
+ * the environment feeds the GEMMs the bounded LayerNorm output instead. */
 int ltr_status(ltr_handle h, void* stream);
 
 /* Same forward stopped after `n_layers` decoder layers (n_layers < 0: all), writing the

@@ -235,7 +235,7 @@ def test_plugin_surface(dev):
     s = Sched()
     s.waiting, s.running, s.swapped = deque(groups), deque(), deque()
     ranker.install(s)
-    assert s._schedule.__func__ is Sched._general_schedule and s.aux_model is ranker and s.starv == 3 and s.period == 2
+    assert s._schedule.__wrapped__.__func__ is Sched._general_schedule and s.aux_model is ranker and s.starv == 3 and s.period == 2
     order = s._get_ordered_requests()
     assert all(g.aux_model_score is not None for g in groups)
     orc = OracleOPTScorer(spec, ckpt)
@@ -289,6 +289,82 @@ def test_plugin_surface(dev):
         MI355XRanker(sc, "fifo").install(Sched())
     with pytest.raises(ValueError):
         MI355XRanker(sc, "xpt-nofile").install(Sched())
+
+
+def test_install_alone_keeps_the_starvation_state_machine_running(dev):
+    """An UNPATCHED reference scheduler (no INTEGRATION.md hunk (b): its aging loop, scheduler.py:1358-1365, touches the
+    host attributes only) behind install(): the wrapped ``_schedule`` ages the device slots from the step's outputs, so
+    ``idle >= starv`` promotions fire exactly where the reference's do.  Also: a scheduler constructed without any
+    ``_update_priority`` (``fcfs``) works (scheduler.py:1103), arrivals inserted in the MIDDLE of ``waiting`` are
+    scored by the fall-back full scan (:971-975), and ``plan_step(ordered=None)`` - permutation kept on the device -
+    equals ``plan_step(ordered_list)``."""
+    from collections import deque
+    from types import SimpleNamespace
+    from oracle import rank_step as rs
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+
+    spec = OPTSpec.tiny_pre_ln()
+    sc = _scorer(spec, seeded_checkpoint(spec, 4), dev, "f16")
+    ranker = MI355XRanker(sc, "opt-xxx-starv3-period2", max_length=100)
+    r = np.random.RandomState(3)
+    mk = lambda i: FakeSeqGroup(str(i), [2] + r.randint(4, spec.vocab_size, r.randint(1, 40)).tolist())
+
+    class Sched:                                             # the shape of Scheduler._general_schedule, host aging only
+        def _general_schedule(self):
+            self._update_priority()                          # :1103
+            order = self._get_ordered_requests()
+            ran = order[:4]
+            for g in ran:
+                if g in self.waiting:
+                    self.waiting.remove(g); self.running.append(g)
+            all_pri = list(self.swapped) + list(self.running) + list(self.waiting)
+            for g in all_pri:                                # the reference's own loop: host attributes
+                if g in ran:
+                    if g.pri == -1:
+                        g.runs -= 1
+                    g.idle = 0
+                else:
+                    g.idle += 1
+            self.last_order = order
+            return SimpleNamespace(scheduled_seq_groups=[SimpleNamespace(seq_group=g) for g in ran])
+    s = Sched()
+    groups = [mk(i) for i in range(24)]
+    s.waiting, s.running, s.swapped = deque(groups), deque(), deque()
+    assert not hasattr(s, "_update_priority")
+    ranker.install(s)
+    mirror = {}
+    promoted = 0
+    for step in range(12):
+        if step == 5:                                        # an arrival that is NOT a suffix of `waiting`
+            g = mk(100); groups.append(g)
+            s.waiting.insert(1, g)
+        concat = list(s.waiting) + list(s.running) + list(s.swapped)
+        ret = s._schedule()
+        for g in concat:
+            mirror.setdefault(g.request_id, rs.Req(g.request_id, g.aux_model_score))
+        lit = rs.opt_order([mirror[g.request_id] for g in concat], 3, 2)
+        assert [g.request_id for g in s.last_order] == [m.request_id for m in lit], step
+        promoted += sum(m.pri == -1 for m in lit)
+        ran_ids = {x.seq_group.request_id for x in ret.scheduled_seq_groups}
+        all_pri = list(s.swapped) + list(s.running) + list(s.waiting)
+        rs.age_update([mirror[g.request_id] for g in all_pri], [mirror[g.request_id] for g in all_pri if g.request_id in ran_ids])
+        ranker.sync_host(all_pri)                            # device slots == the literal state machine
+        assert [(g.pri, g.idle, g.runs) for g in all_pri] == \
+            [(mirror[g.request_id].pri, mirror[g.request_id].idle, mirror[g.request_id].runs) for g in all_pri], step
+    assert promoted > 0                                      # the starvation path was exercised
+    # plan_step with the permutation left on the device == plan_step on the ordered list
+    reqs = list(s.waiting) + list(s.running) + list(s.swapped)
+    n = len(reqs)
+    nt = r.randint(1, 50, n).astype(np.int32); nq = np.ones(n, np.int32)
+    order = ranker.order(reqs)
+    pos = {id(g): i for i, g in enumerate(reqs)}
+    want = ranker.plan_step(order, [nt[pos[id(g)]] for g in order], [nq[pos[id(g)]] for g in order], 120, 6)
+    assert ranker.order(reqs, want_list=False) is None
+    got = ranker.plan_step(None, nt, nq, 120, 6)
+    assert [g.request_id for g in got["ordered"]] == [g.request_id for g in order]
+    assert [g.request_id for g in got["selected"]] == [g.request_id for g in want["selected"]] and got["granted"] == want["granted"]
+    assert len(got["selected"]) > 0
 
 
 def test_plugin_step_time_at_8k(dev):
@@ -387,6 +463,33 @@ def test_outlier_activations(dev, variant):
     rel = float(np.abs(got - want).max()) / scale
     print(f"{variant}: score range {np.abs(want).max():.2f}, max rel err {rel:.2e}")
     assert np.isfinite(got).all() and rel <= 2e-5
+
+
+def test_layernorm_fold_operand_overflow_is_reported(dev, monkeypatch):
+    """The LayerNorm-fold operand is split(x * gamma * 16) of the UN-normalised residual stream: beyond |x gamma| ~ 4094
+    its fp16 hi plane is inf.  That must not pass silently as NaN scores: ltr_status reports it (LTR_E_RANGE), and the
+    same checkpoint scores correctly on a handle without the fold (LTR_NO_LN_FOLD=1: bounded LayerNorm output)."""
+    from vllm_ltr_amd._lib import LtrError
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 31)
+    w = ckpt["model.decoder.embed_positions.weight"].astype(np.float32)
+    w[:, 5] += 8000.0                                       # one massive channel, exact in fp16
+    ckpt["model.decoder.embed_positions.weight"] = w.astype(np.float16)
+    ids, cu = synthetic_batch(spec, [1, 7, 33, 64], seed=9)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    with pytest.raises(LtrError, match="fp16 range"):
+        sc.score(ids, cu)
+    near = dict(ckpt)                                       # just inside the range: no flag, f32-grade scores
+    w2 = seeded_checkpoint(spec, 31)["model.decoder.embed_positions.weight"].astype(np.float32)
+    w2[:, 5] += 2500.0
+    near["model.decoder.embed_positions.weight"] = w2.astype(np.float16)
+    want_near = OracleOPTScorer(spec, near, dtype=torch.float64).score(ids, cu)
+    got_near = _scorer(spec, near, dev, "f16").score(ids, cu)
+    assert np.isfinite(got_near).all() and np.abs(got_near - want_near).max() <= 1e-4 * max(1.0, np.abs(want_near).max())
+    monkeypatch.setenv("LTR_NO_LN_FOLD", "1")
+    got = _scorer(spec, ckpt, dev, "f16").score(ids, cu)
+    want = OracleOPTScorer(spec, ckpt, dtype=torch.float64).score(ids, cu)
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
 @pytest.mark.parametrize("variant,expected,mode", [("st", "expected_class2", "f16"), ("sharded", "expected_class2", "f16"),

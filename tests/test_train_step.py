@@ -128,6 +128,36 @@ def test_hip_training_steps_match_hf_plus_adam(case):
 
 
 @pytest.mark.gpu
+def test_gradient_only_calls_do_not_advance_adam_and_bad_class_labels_raise():
+    """torch.optim.Adam advances its step count in optimizer.step() only: a gradient-only call (apply_update=False,
+    what grads() users make) must leave the bias corrections of the next real update untouched.  And a crossentropy
+    label outside [0, num_labels) - the reference asserts labels.max() < num_labels, trainer.py:151 - is refused."""
+    from vllm_ltr_amd.trainer import HipPredictorTrainer
+    z, spec, loss_name, lr, wd, _ = _load(CASES[0])
+    ckpt = seeded_checkpoint(spec, int(z["seed"]))
+    args = (z["s0_ids"], z["s0_cu"], z["s0_labels"], z["s0_shuffle"])
+    a = HipPredictorTrainer(spec, ckpt, "cuda:0", lr=lr, weight_decay=wd, loss=loss_name)
+    b = HipPredictorTrainer(spec, ckpt, "cuda:0", lr=lr, weight_decay=wd, loss=loss_name)
+    a.step(*args, apply_update=False)
+    a.step(*args, apply_update=False)
+    la = a.step(*args)
+    lb = b.step(*args)
+    assert la == lb
+    sa, sb = a.state(), b.state()
+    for k in sb:
+        assert np.array_equal(sa[k], sb[k]), k
+    zc, cspec, _, clr, cwd, _ = _load("pre_ln_class5_ce")
+    c = HipPredictorTrainer(cspec, seeded_checkpoint(cspec, int(zc["seed"])), "cuda:0", lr=clr, weight_decay=cwd,
+                            loss="crossentropy")
+    lab = np.array(zc["s0_labels"], np.float32)
+    for bad in (float(cspec.num_labels), -1.0, 0.5):
+        wrong = lab.copy(); wrong[1] = bad
+        with pytest.raises(ValueError):
+            c.step(zc["s0_ids"], zc["s0_cu"], wrong, None)
+    assert np.isfinite(c.step(zc["s0_ids"], zc["s0_cu"], lab, None))
+
+
+@pytest.mark.gpu
 def test_hip_trainer_learns_and_round_trips_through_the_serving_path(tmp_path):
     """The recipe end to end on a synthetic task (label = the reference's len2label of a length that the FIRST prompt
     token determines): ListMLE fine-tuning on the device raises Kendall's tau (the trainer's metric, trainer.py:196),

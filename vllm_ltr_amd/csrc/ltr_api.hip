@@ -294,7 +294,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = ab; g.w = m->gemm_lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
-      if (fold_here) { g.ln_gamma = (const float*)m->lw(L, LTR_WL_LN2_W); g.ln_out = ws.a2; g.ln_stats_out = ws.stats2; }
+      if (fold_here) { g.ln_gamma = (const float*)m->lw(L, LTR_WL_LN2_W); g.ln_out = ws.a2; g.ln_stats_out = ws.stats2; g.err_flag = m->err_flag; }
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {   // 350m: LN after the residual add; h and its operand copy
@@ -318,7 +318,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F; g.a_slab = wd == LTR_W_F16;
-      if (ln1_folded) { g.ln_gamma = (const float*)m->lw(L + 1, LTR_WL_LN1_W); g.ln_out = ws.a; g.ln_stats_out = ws.stats1; }
+      if (ln1_folded) { g.ln_gamma = (const float*)m->lw(L + 1, LTR_WL_LN1_W); g.ln_out = ws.a; g.ln_stats_out = ws.stats1; g.err_flag = m->err_flag; }
       if ((rc = gemm(g))) return rc;
     }
     if (!d.pre_ln) {
@@ -503,9 +503,13 @@ int ltr_status(ltr_handle h, void* stream) {
   LTR_HIP_CHECK(hipStreamSynchronize(s));
   if (flag) {
     LTR_HIP_CHECK(hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), s));
-    set_error("ltr_score: a token id outside [0, %d) was fed to the embedding (F.embedding raises on it, "
-              "vocab_parallel_embedding.py:95-106); the scores of that call are invalid", h->d.vocab_size);
-    return LTR_E_INVAL;
+    if (flag & 1)
+      set_error("ltr_score: a token id outside [0, %d) was fed to the embedding (F.embedding raises on it, "
+                "vocab_parallel_embedding.py:95-106); the scores of that call are invalid", h->d.vocab_size);
+    else
+      set_error("ltr_score: the residual stream left the fp16 range of the LayerNorm-fold operand (|x * gamma| > 4094); "
+                "the scores of that call are invalid - create the handle with LTR_NO_LN_FOLD=1 for this checkpoint");
+    return (flag & 1) ? LTR_E_INVAL : LTR_E_RANGE;
   }
   return LTR_OK;
 }

@@ -76,6 +76,7 @@ struct Epilogue {
   const float2* stats_in; // consumer: [n_part][M] pieces of the rows of A
   const float* ln_c;      // consumer: [N] LN_FOLD_SCALE * sum_k gamma_k W[n, k]   (bias then holds beta W + b)
   int n_part;
+  int32_t* err_flag;      // producer: bit 1 is set when |x gamma scale| leaves the fp16 range (ltr_status reports it)
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -417,8 +418,13 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
           // per plane the 8 lanes x 8 rows of one store instruction cover 512 contiguous bytes of a slab.
           const float gs[8] = {lnv_a.x, lnv_a.y, lnv_a.z, lnv_a.w, lnv_b.x, lnv_b.y, lnv_b.z, lnv_b.w};
           __half h[8], l[8];
+          float amax = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) split_f16(x[e] * gs[e], h[e], l[e]);
+          for (int e = 0; e < 8; ++e) { const float xs = x[e] * gs[e]; amax = fmaxf(amax, fabsf(xs)); split_f16(xs, h[e], l[e]); }
+          // The operand carries the UN-normalised residual stream (times gamma, times 16): beyond fp16's 65504 its hi
+          // plane is inf and the scores NaN, where separate LayerNorm launches would still work.  Flag it (NaN fails
+          // the comparison too and is flagged).
+          if (!(amax <= 65504.f) && ep.err_flag) atomicOr(ep.err_flag, 2);
           // lane pair (l, l ^ 1) holds columns {4k..4k+3, 32+4k..} and {4k+4..4k+7, 36+4k..}: swap halves so that the even
           // lane owns 8 consecutive columns of the first slab and the odd lane 8 of the second -> ONE 16-byte store
           // per plane and lane (8-byte stores issue at half the rate per byte)
@@ -611,7 +617,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
-              g.ln_parts};
+              g.ln_parts, g.err_flag};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : LN_NONE);
   if (lnm != LN_NONE) {
     if (wdtype != LTR_W_F16) { set_error("gemm: the LayerNorm fold exists in F16 mode only"); return LTR_E_INVAL; }

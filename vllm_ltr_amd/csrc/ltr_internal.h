@@ -69,6 +69,7 @@ struct GemmArgs {
   const void* ln_stats_in = nullptr; // float2 [K / 64][M]; non-null selects the consumer epilogue
   const float* ln_c = nullptr;       // [N] 16 * sum_k gamma_k W[n, k]; `bias` must then hold sum_k beta_k W[n, k] + b_n
   int ln_parts = 0;                  // K / 64
+  int32_t* err_flag = nullptr;       // producer: device status word (bit 1 = operand left the fp16 range)
 };
 
 // launchers (each in its own .hip file)

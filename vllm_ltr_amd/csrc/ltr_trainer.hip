@@ -193,9 +193,13 @@ __global__ void __launch_bounds__(256) ce_rows_kernel(const float* __restrict__ 
   float s = 0.f;
   for (int j = lane; j < nl; j += 64) s += expf(lr[j] - mx);
   s = wave_sum(s);
-  const int lab = (int)labels[r];
+  // a label outside [0, nl) (the reference asserts labels.max() < num_labels, trainer.py:151; the host mirror raises
+  // before the call) must not index the row: the loss of the step becomes NaN instead
+  const float labf = labels[r];
+  const bool lab_ok = labf >= 0.f && labf < (float)nl;
+  const int lab = lab_ok ? (int)labf : 0;
   for (int j = lane; j < nl; j += 64) dl[(size_t)r * nl + j] = (expf(lr[j] - mx) / s - (j == lab ? 1.f : 0.f)) / (float)N;
-  if (lane == 0) row_loss[r] = logf(s) + mx - lr[lab];
+  if (lane == 0) row_loss[r] = lab_ok ? logf(s) + mx - lr[lab] : __builtin_nanf("");
 }
 __global__ void __launch_bounds__(64) mean_kernel(const float* __restrict__ v, int N, float* __restrict__ out) {
   if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < N; ++i) s += v[i]; *out = s / (float)N; }
@@ -382,7 +386,8 @@ struct ltr_trainer {
   ltr_model_desc d;
   ltr_train_config cfg;
   int device = 0;
-  int64_t step = 0;
+  int64_t step = 0;                    // forward/backward passes so far (seeds the dropout masks)
+  int64_t adam_step = 0;               // optimizer.step() calls so far: torch.optim.Adam advances t only there
   size_t total = 0;
   std::vector<size_t> off, cnt;        // per weight index (ltr_create's index space)
   float *P = nullptr, *G = nullptr, *M1 = nullptr, *V1 = nullptr, *wT = nullptr;
@@ -825,8 +830,9 @@ int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* 
   if ((rc = backward(c, token_ids, cu_seqlens))) return rc;
   h->step += 1;
   if (apply_update) {                                                // optimizer.step() (trainer.py:163)
+    h->adam_step += 1;                                               // gradient-only calls do not advance Adam's t
     const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
-    const float bc1 = (float)(1.0 - std::pow(b1, (double)h->step)), bc2 = (float)(1.0 - std::pow(b2, (double)h->step));
+    const float bc1 = (float)(1.0 - std::pow(b1, (double)h->adam_step)), bc2 = (float)(1.0 - std::pow(b2, (double)h->adam_step));
     adam_kernel<<<2048, 256, 0, s>>>(h->P, h->G, h->M1, h->V1, h->total, h->cfg.lr, h->cfg.beta1, h->cfg.beta2, h->cfg.eps,
                                      h->cfg.weight_decay, bc1, bc2);
     LTR_LAUNCH_CHECK();

@@ -41,10 +41,12 @@ def shard_bounds(cu_seqlens: np.ndarray, world: int) -> List[Tuple[int, int]]:
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
-def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All-gather variable-length f32 score shards: pad to the longest shard, one
     ``all_gather_into_tensor``, drop the padding.  ``counts[r]`` = shard length of rank r
-    (known to every rank)."""
+    (known to every rank).  ``out`` f32 [sum(counts)]: the compaction writes straight into it (the queue's
+    score slots) instead of a fresh tensor that would have to be copied there."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     assert len(counts) == world
@@ -56,12 +58,15 @@ def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None) -> tor
         # (tests, LTR_BENCH_BACKEND=gloo) comes here; production is RCCL ("nccl") on device buffers.
         out_h = torch.empty(world * mx, dtype=torch.float32)
         dist.all_gather_into_tensor(out_h, buf.cpu(), group=group)
-        out = out_h.to(local.device)
+        out_g = out_h.to(local.device)
     else:
-        out = torch.empty(world * mx, dtype=torch.float32, device=local.device)
-        dist.all_gather_into_tensor(out, buf, group=group)
-    out = out.view(world, mx)
-    return torch.cat([out[r, :counts[r]] for r in range(world)])
+        out_g = torch.empty(world * mx, dtype=torch.float32, device=local.device)
+        dist.all_gather_into_tensor(out_g, buf, group=group)
+    g = out_g.view(world, mx)
+    parts = [g[r, :counts[r]] for r in range(world)]
+    if out is not None:
+        return torch.cat(parts, out=out)
+    return torch.cat(parts)
 
 
 class ShardedScorer:
@@ -87,24 +92,39 @@ class ShardedScorer:
         self.world = dist.get_world_size(group)
         self.min_requests_to_shard = int(min_requests_to_shard)
 
-    # ---- the collective part (same on both entry points)
-    def _exchange(self, n: int, sharded: bool, bounds, local_fn, whole_fn) -> torch.Tensor:
+    def any_rank(self, flag: bool) -> bool:
+        """True on every rank iff ``flag`` is true on at least one (one 4-byte all-reduce): lets all ranks of an SPMD
+        call agree on an error before any of them raises."""
         if self.world == 1:
-            return whole_fn()
+            return bool(flag)
+        on_dev = self.dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
+    # ---- the collective part (same on both entry points)
+    def _exchange(self, n: int, sharded: bool, bounds, local_fn, whole_fn, out=None) -> torch.Tensor:
+        if self.world == 1:
+            return whole_fn(out)
         if not sharded:                                  # same decision on every rank (same n)
             if self.rank == 0:
-                s = whole_fn().to(self.device, torch.float32)
+                s = whole_fn(out).to(self.device, torch.float32)
             else:
-                s = torch.empty(n, dtype=torch.float32, device=self.device)
-            self.dist.broadcast(s, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
-                                group=self.group)
+                s = out if out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+            src = self.dist.get_global_rank(self.group, 0) if self.group else 0
+            if s.is_cuda and self.dist.get_backend(self.group) != "nccl":     # one-device dry run (see gather_scores)
+                h = s.cpu()
+                self.dist.broadcast(h, src=src, group=self.group)
+                s.copy_(h)
+            else:
+                self.dist.broadcast(s, src=src, group=self.group)
             return s
         r0, r1 = bounds[self.rank]
         if r1 > r0:
             local = local_fn(r0, r1).to(self.device, torch.float32)
         else:
             local = torch.zeros(0, dtype=torch.float32, device=self.device)
-        return gather_scores(local, [b - a for a, b in bounds], self.group)
+        return gather_scores(local, [b - a for a, b in bounds], self.group, out=out)
 
     def _local_host(self, ids, cu):
         if self.scorer is not None:
@@ -124,11 +144,13 @@ class ShardedScorer:
         ids = np.asarray(ids)
         return self._exchange(n, sharded, bounds,
                               lambda r0, r1: self._local_host(ids[cu[r0]:cu[r1]], cu[r0:r1 + 1] - cu[r0]),
-                              lambda: self._local_host(ids, cu))
+                              lambda out=None: self._local_host(ids, cu))
 
-    def score_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray) -> torch.Tensor:
+    def score_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The whole batch is resident on every rank's device (ids int64 [T], cu int32 [N+1] + host mirror);
-        each rank scores its slice of it in place - no copies, one all-gather of the scores."""
+        each rank scores its slice of it in place - no copies, one all-gather of the scores.  ``out`` f32 [N] on the
+        device: where the gathered scores go (e.g. the queue's score slots)."""
         assert self.scorer is not None, "score_device needs a device scorer"
         cu = np.asarray(cu_host, dtype=np.int64)
         n = cu.shape[0] - 1
@@ -143,4 +165,5 @@ class ShardedScorer:
             cu_d = cu_dev[r0:r1 + 1] - t0 if t0 else cu_dev[r0:r1 + 1]
             return self.scorer.score_device(ids_dev[t0:int(cu[r1])], cu_d.contiguous(), cu_s)
         return self._exchange(n, sharded, bounds, local,
-                              lambda: self.scorer.score_device(ids_dev, cu_dev, np.ascontiguousarray(cu_host, np.int32)))
+                              lambda out=None: self.scorer.score_device(ids_dev, cu_dev, np.ascontiguousarray(cu_host, np.int32),
+                                                                        out=out), out=out)

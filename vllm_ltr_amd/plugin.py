@@ -152,6 +152,9 @@ class MI355XRanker:
         self._n_members = 0
         self._members_dev: Optional[torch.Tensor] = None
         self._live_slots = 0
+        self._aged = True                    # False between an order() and the age() that belongs to it
+        self._last_reqs: Sequence = ()
+        self._last_perm_dev: Optional[torch.Tensor] = None
         self.stats = dict(aux_calls=0, requests_scored=0, rank_calls=0, score_seconds=0.0, rank_seconds=0.0)
 
     # ---- construction from the reference's config objects ------------------------------
@@ -247,7 +250,7 @@ class MI355XRanker:
         slots = torch.from_numpy(np.fromiter(map(self._get_slot, seq_groups), np.int64, len(seq_groups))).to(self.device)
         self.queue.set_scores(slots, scores_dev)
         scores = self._stager.fetch_scores(scores_dev)
-        self.scorer.check_status()                         # out-of-vocabulary ids raise, like F.embedding
+        self._check_status()                               # out-of-vocabulary ids raise, like F.embedding
         out = scores.tolist()                              # opt.py:408 .tolist()
         for sg, s in zip(seq_groups, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
@@ -256,12 +259,34 @@ class MI355XRanker:
         self.stats["score_seconds"] += time.perf_counter() - t0
         return out
 
+    def _check_status(self) -> None:
+        """Raise where the reference's F.embedding raises (a token id outside the vocabulary).  With ``group=`` the
+        flag lives on the rank whose shard held the id: the ranks agree on it first (one tiny all-reduce), so that
+        EVERY rank raises - a rank that carried on alone would enter the next collective without its peers."""
+        err = None
+        try:
+            self.scorer.check_status()
+        except _lib.LtrError as e:
+            err = e
+        if self._sharded is not None and self._sharded.any_rank(err is not None) and err is None:
+            err = _lib.LtrError("ltr_score: another rank of the group met a token id outside the predictor's vocabulary "
+                                "(F.embedding raises on it, vocab_parallel_embedding.py:95-106); the scores of this "
+                                "call are invalid on every rank")
+        if err is not None:
+            raise err
+
     # ---- Scheduler._get_*_ordered_requests ------------------------------------------------
-    def order(self, reqs: Sequence, policy: Optional[str] = None) -> list:
+    def order(self, reqs: Sequence, policy: Optional[str] = None, want_list: bool = True) -> Optional[list]:
         """Promote/demote (when starvation control is on) and order ``reqs`` (already the
         concatenation waiting+running+swapped, all scored); scheduler.py:984-998.  The counters are
-        updated in the device-resident slots (see :meth:`sync_host`)."""
+        updated in the device-resident slots (see :meth:`sync_host`).
+
+        ``want_list=False``: leave the permutation on the device and return None - for a caller that goes straight
+        to :meth:`plan_step` ``(ordered=None, ...)``, which brings the permutation back together with the selection
+        in ONE copy (no synchronisation here)."""
         n = len(reqs)
+        self._aged = False           # install(): the wrapped _schedule ages the device slots if nobody calls age()
+        self._last_reqs, self._last_perm_dev = reqs, None
         if n == 0:
             self._n_members = 0
             return []
@@ -285,6 +310,11 @@ class MI355XRanker:
                 tiebreak = torch.from_numpy(_string_rank([r.request_id for r in reqs])).to(self.device)
             rank_step(q._score, None, None, None, -1, 0, self._ws, tiebreak=tiebreak,
                       ascending=policy in ("ropt", "rtpt"), out=perm_dev, members=members)   # scheduler.py:961,1015
+        self._last_perm_dev = perm_dev
+        if not want_list:
+            self.stats["rank_calls"] += 1
+            self.stats["rank_seconds"] += time.perf_counter() - t0
+            return None
         host = self._perm.host[:n]
         host.copy_(perm_dev, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
@@ -335,7 +365,17 @@ class MI355XRanker:
             if timed:
                 print("OPT-TIME: ", time.time() - t0)
         reqs = list(waiting) + list(scheduler.running) + list(scheduler.swapped)
-        out = self.order(reqs, policy)
+        try:
+            out = self.order(reqs, policy)
+        except TypeError:
+            # an unscored request that is NOT in the tail of `waiting` (a scheduler that inserts arrivals elsewhere):
+            # do what the reference does - scan the whole deque (:971-975) - and order again.  Unscored requests in
+            # `running` / `swapped` still fail, like the reference's sorted() on -None.
+            need = [r for r in waiting if r.need_aux_model_score()]
+            if not need:
+                raise
+            scheduler.aux_model.obtain_aux_scores(need)
+            out = self.order(reqs, policy)
         self._gc_slots(len(reqs))        # `reqs` is every live request here (not so for direct order() calls on a subset)
         return out
 
@@ -344,6 +384,7 @@ class MI355XRanker:
         """scheduler.py:1358-1365, computed by ltr_age_update on the device-resident slots: only the slots of
         ``running_this_step`` (<= max_num_seqs) are uploaded; the members of the step are the ones
         :meth:`order` ranked (``all_pri`` is the same set, scheduler.py:1337-1338)."""
+        self._aged = True
         n = len(all_pri)
         if n == 0:
             return
@@ -394,32 +435,52 @@ class MI355XRanker:
         ``swap_out`` = unselected running requests to swap out, lowest priority first;
         ``put_back`` = selected requests dropped from the selection, last selected first;
         ``execute``  = ``execute_pinned_requests``."""
-        n = len(ordered)
-        if n == 0:
-            return dict(selected=[], granted=[], swap_out=[], put_back=[], execute=[])
         dev = self.device
         i32 = lambda a: torch.from_numpy(np.asarray(a, np.int32)).to(dev)
-        perm = torch.arange(n, dtype=torch.int32, device=dev)       # `ordered` is already in rank order
+        if ordered is None:
+            # straight from order(..., want_list=False): the permutation is still on the device and every per-element
+            # sequence is indexed by CONCATENATION position (waiting+running+swapped, the list order() was given);
+            # the ranked list comes back with the decisions in the one copy below
+            reqs, perm = self._last_reqs, self._last_perm_dev
+            if perm is None:
+                raise ValueError("plan_step(ordered=None) needs a preceding order(..., want_list=False)")
+            n = len(reqs)
+        else:
+            n = len(ordered)
+            perm = torch.arange(n, dtype=torch.int32, device=dev) if n else None   # `ordered` is already in rank order
+        if n == 0:
+            return dict(selected=[], granted=[], swap_out=[], put_back=[], execute=[], ordered=[])
         nt, nq = i32(new_tokens), i32(new_seqs)
         ck = None if chunkable is None else torch.from_numpy(np.asarray(chunkable, np.uint8)).to(dev)
         n_sel, _, granted = budget_prefix(perm, nt, nq, token_budget, max_num_seqs, want_ran=False, chunkable=ck)
+        parts = [n_sel, granted]
+        if blocks is not None:
+            state = torch.from_numpy(np.asarray(blocks["state"], np.uint8)).to(dev)
+            action, n_exec, _ = reserve_select(perm, n_sel, state, i32(blocks["phys"]), i32(blocks["logical"]),
+                                               i32(blocks["nrun"]), i32(blocks["nswap"]),
+                                               int(blocks["free"]) - int(blocks["watermark"]), new_seqs=nq)
+            parts += [n_exec, action.to(torch.int32)]
+        if ordered is None:
+            parts.append(perm)
+        host = torch.cat(parts).cpu().numpy()                       # the one D2H copy of the step
+        k = int(host[0])
+        if ordered is None:
+            p = host[-n:]
+            ordered = list(operator.itemgetter(*p.tolist())(reqs)) if n > 1 else [reqs[int(p[0])]]
+            by_rank = lambda a: a[p]                                # per-request outputs are indexed by position
+        else:
+            by_rank = lambda a: a
+        g = by_rank(host[1:1 + n])
         if blocks is None:
-            k = int(n_sel.item())
-            g = granted[:k].cpu().numpy()
             sel = list(ordered[:k])
-            return dict(selected=sel, granted=g.tolist(), swap_out=[], put_back=[], execute=sel)
-        state = torch.from_numpy(np.asarray(blocks["state"], np.uint8)).to(dev)
-        action, n_exec, _ = reserve_select(perm, n_sel, state, i32(blocks["phys"]), i32(blocks["logical"]),
-                                           i32(blocks["nrun"]), i32(blocks["nswap"]),
-                                           int(blocks["free"]) - int(blocks["watermark"]), new_seqs=nq)
-        host = torch.cat([n_sel, n_exec, granted, action.to(torch.int32)]).cpu().numpy()
-        k, ke = int(host[0]), int(host[1])
-        g, act = host[2:2 + n], host[2 + n:]
+            return dict(selected=sel, granted=g[:k].tolist(), swap_out=[], put_back=[], execute=sel, ordered=ordered)
+        ke = int(host[1 + n])
+        act = by_rank(host[2 + n:2 + 2 * n])
         sel = list(ordered[:k])
         swap_out = [ordered[i] for i in range(n - 1, k - 1, -1) if act[i] == 1]
         put_back = [ordered[i] for i in range(k - 1, -1, -1) if act[i] in (2, 3)]
         return dict(selected=sel, granted=g[:k].tolist(), swap_out=swap_out, put_back=put_back,
-                    execute=sel[:ke])
+                    execute=sel[:ke], ordered=ordered)
 
     # ---- wiring ------------------------------------------------------------------------------
     def install(self, scheduler) -> None:
@@ -440,5 +501,21 @@ class MI355XRanker:
         if self.st.starv != -1:
             scheduler.period = self.st.period
         if hasattr(scheduler, "_general_schedule"):
-            scheduler._schedule = scheduler._general_schedule                    # scheduler.py:313,320,326
+            # scheduler.py:313,320,326 bind _schedule = _general_schedule.  The starvation counters live in the device
+            # slots, so the aging of :1358-1365 must reach them: a scheduler patched with INTEGRATION.md hunk (b)
+            # calls self.age(all_pri, running_this_step) itself; on an UNPATCHED reference scheduler (its loop ages the
+            # host attributes only) the wrapper below does it from the step's outputs - install() alone is enough.
+            inner = scheduler._general_schedule
+
+            def _schedule_and_age():
+                ret = inner()
+                if not self._aged:
+                    all_pri = list(scheduler.swapped) + list(scheduler.running) + list(scheduler.waiting)   # :1337
+                    self.age(all_pri, [r.seq_group for r in getattr(ret, "scheduled_seq_groups", ())])
+                return ret
+            _schedule_and_age.__wrapped__ = inner
+            scheduler._schedule = _schedule_and_age
+        # _general_schedule starts with self._update_priority() (:1103); every score-ordered policy binds a no-op
+        # there (:935,950,965,1002,1017) - a scheduler built as `fcfs` and given a ranker afterwards has none
+        scheduler._update_priority = lambda: None
         scheduler._get_ordered_requests = lambda: self.ordered_requests(scheduler, policy)

@@ -105,8 +105,19 @@ class HipPredictorTrainer:
         dev = self.device
         ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(dev)
         cu_d = torch.from_numpy(cu).to(dev)
-        lab_d = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.float32)).to(dev)
-        assert lab_d.numel() == N
+        lab = np.ascontiguousarray(labels, dtype=np.float32)
+        if lab.size != N:
+            raise ValueError(f"{lab.size} labels for a slate of {N} prompts")
+        if self.loss == "crossentropy":
+            # class indices: the reference asserts labels.max() < num_labels (trainer.py:151); the kernel indexes the
+            # logits row with them, so a label outside [0, num_labels) must never reach it
+            bad = (lab != np.floor(lab)) | (lab < 0) | (lab >= self.spec.num_labels)
+            if bad.any():
+                i = int(np.nonzero(bad)[0][0])
+                raise ValueError(f"crossentropy label {lab[i]!r} of prompt {i} is not a class index in "
+                                 f"[0, {self.spec.num_labels}) (len2label with a mismatched label_max_length / "
+                                 "label_group_size produces such labels; trainer.py:50-52,151)")
+        lab_d = torch.from_numpy(lab).to(dev)
         sh_d = None
         if self.loss == "listMLE":
             sh = np.random.permutation(N) if shuffle is None else np.asarray(shuffle)
