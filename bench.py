@@ -11,19 +11,28 @@ One "step" = one COLD ranker call on the synthetic queue (every request unscored
 predictor forward over all prompts (ltr_score) -> [N>1: RCCL all-gather of the score
 shards] -> ltr_queue_step = starvation promote/demote + priority sort, budget-walk
 prefix, aging (two launches).  Inputs (token ids, cu_seqlens, queue state) are resident in
-HBM before the timed region.  N>1 is weak scaling and runs the PRODUCT's sharding logic
-(vllm_ltr_amd.distributed.ShardedScorer): one global queue of N*8k requests known to every
-rank (BASELINE config 4 at N=8), token-balanced contiguous shards from the shared
-cu_seqlens, each rank scores its shard, one all-gather of f32 scores, and every rank runs
-the same deterministic rank step on the whole gathered queue.
+HBM before the timed region.  N>1 runs the PRODUCT's sharding logic
+(vllm_ltr_amd.distributed.ShardedScorer): one global queue known to every rank,
+token-balanced contiguous shards from the shared cu_seqlens, each rank scores its shard, one
+all-gather of f32 scores, and every rank runs the same deterministic rank step on the whole
+gathered queue.
 
-Rank 0 prints one JSON line (contract in the task statement) with `roofline` for the
-dominant kernel and `cpu_baseline` (the oracle = CPU restatement of the reference, timed
-on this host on a bounded sample).
+* default (weak scaling): N x 8k requests (BASELINE config 2 at N = 1, config 4 - the 64k queue - at N = 8);
+* ``--queue-total Q`` (strong scaling): a FIXED queue of Q requests at every N - north_star's "1k-64k-request queues
+  at 1/2/4/8 GPUs"; the default run also carries the Q = 65,536 point of that table in ``strong_scaling``;
+* ``--sweep``: one extra JSON line (printed first) with the cold call at 256 ... 64k requests on this world size;
+* ``--trace burst|gamma``: BASELINE config 5, ranker side - replays an arrival trace through the scheduler plug-in
+  (vllm_ltr_amd.replay) and prints the ranker's latency distribution per scheduler step instead of the headline line.
+
+The timed region runs with the library's event profiler OFF; the per-kernel breakdown and ``roofline`` come from a
+second pass of the same K steps with it on (``profiled_ms_per_step`` next to ``ms_per_step``).  Rank 0 prints one JSON
+line (contract in the task statement) with ``roofline`` for the dominant kernel and ``cpu_baseline`` (the oracle = CPU
+restatement of the reference, timed on this host on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -42,6 +51,16 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec
 
 
 PROFILES = {"sharegpt": 64.0, "lmsys": 128.0}     # median prompt length of the lognormal profile
+# sources whose text decides what the PMC passes under profiles/ measured (profiles/make_traffic.py stamps their hash)
+PMC_SOURCES = ("vllm_ltr_amd/csrc/ltr_gemm.hip", "vllm_ltr_amd/csrc/ltr_api.hip")
+
+
+def kernel_sources_sha16() -> str:
+    h = hashlib.sha256()
+    for rel in PMC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_queue(spec: OPTSpec, n: int, seed: int, profile: str = "sharegpt"):
@@ -105,12 +124,100 @@ def cpu_baseline(spec, ckpt, ids, cu, starv, period, budget_s: float = 12.0):
                        f"forward packed<=2048 tok ({t_score:.2f}s) + literal Python rank/age ({t_rank*1e3:.2f}ms)")
 
 
+class ColdCall:
+    """One global queue of ``n_total`` requests, resident on every rank, and its cold ranker call."""
+
+    def __init__(self, spec, scorer, dev, dist, world, rank, n_total, profile, min_shard, starv, period, seed=0):
+        from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
+        from vllm_ltr_amd.rank import DeviceQueue
+        self.scorer, self.dev, self.dist, self.world, self.rank, self.n_total = scorer, dev, dist, world, rank, n_total
+        self.ids, self.cu, self.lens = synthetic_queue(spec, n_total, seed=seed, profile=profile)
+        self.ids_d = torch.from_numpy(self.ids).to(dev)
+        self.cu_d = torch.from_numpy(self.cu).to(dev)
+        self.sharded = ShardedScorer(scorer, dev, min_requests_to_shard=min_shard) if world > 1 else None
+        self.r0, self.r1 = shard_bounds(self.cu, world)[rank] if world > 1 and n_total >= min_shard else (0, n_total)
+        self.queue = DeviceQueue(dev, starv=starv, period=period, capacity=n_total)
+        self.queue.append(torch.zeros(n_total))
+        self.need_tokens = torch.from_numpy(self.lens.astype(np.int32)).to(dev)
+        self.need_seqs = torch.ones(n_total, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(n_total, dtype=torch.int32, device=dev)
+
+    def rank_part(self):
+        # promote/demote + sort, budget-walk prefix, aging: ltr_queue_step, two launches
+        self.queue.step(self.need_tokens, self.need_seqs, 2048, 256, perm_out=self.perm)
+
+    def step(self):
+        out = self.queue._score[:self.n_total]
+        if self.sharded is not None:
+            # the one exchange step of the path: RCCL all-gather of f32 score shards over xGMI, compacted straight
+            # into the queue's score slots
+            self.sharded.score_device(self.ids_d, self.cu_d, self.cu, out=out)
+        else:
+            self.scorer.score_device(self.ids_d, self.cu_d, self.cu, out=out)
+        self.rank_part()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """W untimed + exactly K timed steps between barrier + synchronize; returns (max-over-ranks seconds, sorted
+        per-step ms from events on this rank)."""
+        for _ in range(warmup):
+            self.step()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        self.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            self.step()
+            ev[k][1].record()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item()), sorted(a.elapsed_time(b) for a, b in ev)
+
+    def release(self):
+        del self.ids_d, self.cu_d, self.queue, self.need_tokens, self.need_seqs, self.perm
+
+
+def run_trace(args, spec, ckpt, dev):
+    """BASELINE config 5, ranker side: k arrivals -> obtain_aux_scores(k) + order + budget walk + age per scheduler step."""
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype)
+    ranker = MI355XRanker(scorer, f"opt-xxx-starv{args.starv}-period{args.period}", max_length=1024)
+    reqs = synthetic_trace(spec.vocab_size, args.trace_requests, args.trace, args.trace_rate, args.trace_cv, seed=0,
+                           prompt_median=PROFILES[args.profile])
+    # warm the kernels / allocator on a throw-away ranker-sized call
+    warm = synthetic_trace(spec.vocab_size, 64, "burst", seed=7)
+    ranker.obtain_aux_scores(warm)
+    res = replay(ranker, reqs, backbone_ms=args.trace_backbone_ms)
+    s = summarize(res)
+    out = {"metric": "ranker latency per scheduler step under an arrival trace (obtain_aux_scores + order + budget walk + aging "
+                     "through MI355XRanker.install)",
+           "value": s["ranker_ms_all"]["p50"], "unit": "ms", "higher_is_better": False, "n_gpus": 1,
+           "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt / output lengths)",
+           "config": {"workload": f"OPT-{args.model} predictor, {args.trace} trace of {args.trace_requests} requests"
+                                  + (f" at {args.trace_rate} req/s, cv {args.trace_cv}" if args.trace == "gamma" else " at t = 0")
+                                  + f", stand-in backbone step {args.trace_backbone_ms} ms, budget 2048 tokens / 256 seqs",
+                      "starv": args.starv, "period": args.period},
+           "trace": s}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queue", type=int, default=8192, help="requests per GPU")
+    ap.add_argument("--queue", type=int, default=8192, help="requests per GPU (weak scaling)")
+    ap.add_argument("--queue-total", type=int, default=0,
+                    help="fixed total queue at every N (strong scaling; overrides --queue)")
     ap.add_argument("--model", default="125m", choices=["125m", "350m"])
     ap.add_argument("--profile", default="sharegpt", choices=sorted(PROFILES),
                     help="prompt-length profile: sharegpt = ln 64 (BASELINE config 2), lmsys = ln 128 (config 3 with --model 350m)")
@@ -121,11 +228,20 @@ def main():
     ap.add_argument("--no-unfused", action="store_true",
                     help="skip the extra forward with separate LayerNorm launches (roofline.unfused): keeps a rocprofv3 "
                          "trace / PMC pass of this command to the launches of the timed configuration")
+    ap.add_argument("--no-profile-pass", action="store_true",
+                    help="skip the second, event-profiled pass (roofline / kernels become null): for rocprofv3 runs")
     ap.add_argument("--starv", type=int, default=200)
     ap.add_argument("--period", type=int, default=10)
-    ap.add_argument("--steady-new", type=int, default=0,
-                    help="also time the steady call with this many new requests (SURVEY 8d: 256); off by default so "
-                         "that a rocprofv3 trace of the default command holds the cold-call launches only")
+    ap.add_argument("--steady-new", default="1,16,64,256",
+                    help="steady calls to time outside the timed region: k new requests scored + the whole queue re-ranked "
+                         "(SURVEY 8d 'steady'); comma list, '0' = none")
+    ap.add_argument("--no-strong", action="store_true", help="skip the 65,536-request strong-scaling point")
+    ap.add_argument("--sweep", action="store_true", help="extra JSON line: cold call at 256 ... 64k requests")
+    ap.add_argument("--trace", default=None, choices=["burst", "gamma"], help="config 5 ranker-side trace replay")
+    ap.add_argument("--trace-requests", type=int, default=2000)
+    ap.add_argument("--trace-rate", type=float, default=16.0)
+    ap.add_argument("--trace-cv", type=float, default=1.0)
+    ap.add_argument("--trace-backbone-ms", type=float, default=25.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,50 +265,38 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
-    from vllm_ltr_amd.rank import DeviceQueue
     from vllm_ltr_amd.scorer import HipOPTScorer
 
     spec = OPTSpec.opt_125m() if args.model == "125m" else OPTSpec.opt_350m()
     ckpt = seeded_checkpoint(spec, 0)
+    if args.trace:
+        return run_trace(args, spec, ckpt, dev)
     scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)
 
-    # ONE global queue of args.queue requests per GPU, identical on every rank (SPMD: all ranks derive the shard
-    # map from the same cu_seqlens); the whole batch is resident on every rank, each rank scores its slice
-    n_local = args.queue
-    n_total = n_local * world
-    ids, cu, lens = synthetic_queue(spec, n_total, seed=0, profile=args.profile)
-    ids_d = torch.from_numpy(ids).to(dev)
-    cu_d = torch.from_numpy(cu).to(dev)
-    sharded = ShardedScorer(scorer, dev, min_requests_to_shard=args.min_shard) if world > 1 else None
-    my_r0, my_r1 = shard_bounds(cu, world)[rank] if world > 1 and n_total >= args.min_shard else (0, n_total)
-    queue = DeviceQueue(dev, starv=args.starv, period=args.period, capacity=n_total)
-    queue.append(torch.zeros(n_total))
-    need_tokens = torch.from_numpy(lens.astype(np.int32)).to(dev)
-    need_seqs = torch.ones(n_total, dtype=torch.int32, device=dev)
-    perm = torch.empty(n_total, dtype=torch.int32, device=dev)
+    strong = args.queue_total > 0
+    n_total = args.queue_total if strong else args.queue * world
+    n_local = n_total // world if strong else args.queue
+    mk = lambda n: ColdCall(spec, scorer, dev, dist, world, rank, n, args.profile, args.min_shard, args.starv, args.period)
 
-    def rank_part():
-        # promote/demote + sort, budget-walk prefix, aging: ltr_queue_step, two launches
-        queue.step(need_tokens, need_seqs, 2048, 256, perm_out=perm)
+    if args.sweep:
+        pts = []
+        for n in (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+            c = mk(n)
+            k = 3 if n <= 16384 else 2
+            el, _ = c.timed(k, 1)
+            pts.append(dict(queue_total=n, tokens_total=int(c.cu[-1]), ms_per_call=el / k * 1e3, requests_per_s=n * k / el,
+                            sharded=bool(world > 1 and n >= args.min_shard)))
+            c.release(); del c
+        if rank == 0:
+            print(json.dumps({"kind": "queue_sweep", "n_gpus": world, "model": args.model, "profile": args.profile,
+                              "scaling": "strong", "points": pts}))
 
-    def step():
-        if sharded is not None:
-            # the one exchange step of the path: RCCL all-gather of f32 score shards over xGMI
-            sharded_scores = sharded.score_device(ids_d, cu_d, cu)
-            queue._score[:n_total].copy_(sharded_scores)
-        else:
-            scorer.score_device(ids_d, cu_d, cu, out=queue._score[:n_total])
-        rank_part()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    call = mk(n_total)
+    ids, cu, lens = call.ids, call.cu, call.lens
+    my_r0, my_r1 = call.r0, call.r1
     for _ in range(args.warmup):
-        step()
-    barrier()
+        call.step()
+    call.barrier()
     # The GEMM launches of the default build also carry the LayerNorm work (LayerNorm fold, ltr_gemm.hip), so their
     # FLOP rate is not comparable with a plain GEMM's.  For the record, time the same call once more on a second handle
     # with the fold off (LTR_NO_LN_FOLD is read at ltr_create): `roofline.unfused` below.  Outside the timed region.
@@ -206,7 +310,7 @@ def main():
             del os.environ["LTR_NO_LN_FOLD"]
         tmp = torch.empty(my_r1 - my_r0, dtype=torch.float32, device=dev)
         cu_loc = np.ascontiguousarray(cu[my_r0:my_r1 + 1] - cu[my_r0]).astype(np.int32)
-        ids_loc, cu_loc_d = ids_d[int(cu[my_r0]):int(cu[my_r1])], torch.from_numpy(cu_loc).to(dev)
+        ids_loc, cu_loc_d = call.ids_d[int(cu[my_r0]):int(cu[my_r1])], torch.from_numpy(cu_loc).to(dev)
         sc2.score_device(ids_loc, cu_loc_d, cu_loc, out=tmp)
         sc2.profile(True); sc2.profile_read(reset=True)
         for _ in range(2):
@@ -216,131 +320,149 @@ def main():
                        gemm_tflops=pu["gemm"]["work"] / (pu["gemm"]["ms"] * 1e-3) / 1e12,
                        frac=pu["gemm"]["work"] / (pu["gemm"]["ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS)
         sc2.close(); del sc2, tmp
-    barrier()
-    scorer.profile(True)
-    scorer.profile_read(reset=True)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step()
-        ev[k][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = scorer.profile_read(reset=True)
+    # ---- the timed region: exactly K steps, event profiler OFF
     scorer.profile(False)
-    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    elapsed, step_ms = call.timed(args.steps, 0)
+    # ---- second pass of the same K steps with the library's event profiler on: per-class kernel time (HIP events on
+    # the launch stream around every launch) for `roofline` and `kernels`
+    prof, prof_elapsed = None, None
+    if not args.no_profile_pass:
+        scorer.profile(True)
+        scorer.profile_read(reset=True)
+        prof_elapsed, _ = call.timed(args.steps, 0)
+        prof = scorer.profile_read(reset=True)
+        scorer.profile(False)
     # rank-only latency (steady call with nothing new to score), measured outside the timed region
     rk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for a, b in rk:
         a.record()
-        rank_part()
+        call.rank_part()
         b.record()
     torch.cuda.synchronize()
     rank_ms = sorted(a.elapsed_time(b) for a, b in rk)
-    # steady call with k = 256 new requests: score the first 256 of the local queue,
-    # then promote/demote + sort + budget prefix + aging over the whole queue
-    k_new = min(args.steady_new, n_local)
-    steady_k_ms = []
-    cu_k = np.ascontiguousarray(cu[:k_new + 1])
-    ids_k, cu_k_d = ids_d[:int(cu_k[-1])], cu_d[:k_new + 1]
-    sk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10 if k_new else 0)]
-    for i, (a, b) in enumerate(sk):
-        a.record()
-        scorer.score_device(ids_k, cu_k_d, cu_k, out=queue._score[:k_new])
-        rank_part()
-        b.record()
-    torch.cuda.synchronize()
-    if k_new:
-        steady_k_ms = sorted(a.elapsed_time(b) for a, b in sk[2:])
+    # steady calls with k new requests: score the first k of the local queue on THIS GPU, then
+    # promote/demote + sort + budget prefix + aging over the whole queue - what a scheduler step with k arrivals pays
+    steady = {}
+    for k_new in [int(x) for x in args.steady_new.split(",") if x.strip() and int(x) > 0]:
+        k_new = min(k_new, n_total)
+        cu_k = np.ascontiguousarray(cu[:k_new + 1])
+        ids_k, cu_k_d = call.ids_d[:int(cu_k[-1])], call.cu_d[:k_new + 1]
+        sk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+        for a, b in sk:
+            a.record()
+            scorer.score_device(ids_k, cu_k_d, cu_k, out=call.queue._score[:k_new])
+            call.rank_part()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in sk[2:])
+        steady[str(k_new)] = ms[len(ms) // 2]
+    call.barrier()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # ---- north_star's strong-scaling table, the 64k point: the SAME fixed 65,536-request queue at every N
+    strong_pt = None
+    if not args.no_strong and not strong and not args.sweep:
+        call.release()
+        c64 = mk(65536)
+        el, _ = c64.timed(2, 1)
+        strong_pt = dict(queue_total=65536, tokens_total=int(c64.cu[-1]), n_gpus=world, ms_per_call=el / 2 * 1e3,
+                         requests_per_s=65536 * 2 / el, scaling="strong",
+                         tokens_rank0_shard=int(c64.cu[c64.r1] - c64.cu[c64.r0]))
+        c64.release(); del c64
 
     if rank == 0:
         lin, att = model_flops(spec, lens[my_r0:my_r1])        # this rank's shard: what its profiler timed
-        gemm = prof["gemm"]
-        gemm_tflops = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
-        kernels = {}
-        for k, v in prof.items():
-            if v["launches"] == 0:
-                continue
-            rate = v["work"] / (v["ms"] * 1e-3)
-            if k in ("gemm", "attn"):
-                kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
-                                  tflops=rate / 1e12)
-            else:
-                kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
-                                  gbs=rate / 1e9, frac_hbm=rate / 1e9 / PEAK_HBM_GBS)
-        if "embed" in kernels:
-            # SURVEY.md 8d counts 4616 B per token for the gather (a 2-byte activation row out); this kernel writes an
-            # f32 residual row (6152 B, the `gbs` above).  The fraction on SURVEY's own bytes:
-            w = 2.0 if args.weight_dtype == "f16" else 4.0
-            survey_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * w
-            ours_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * 4.0
-            kernels["embed"]["frac_hbm_survey_bytes"] = kernels["embed"]["frac_hbm"] * survey_b / ours_b
+        kernels, roof = {}, None
+        if prof is not None:
+            gemm = prof["gemm"]
+            gemm_tflops = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
+            for k, v in prof.items():
+                if v["launches"] == 0:
+                    continue
+                rate = v["work"] / (v["ms"] * 1e-3)
+                if k in ("gemm", "attn"):
+                    kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
+                                      tflops=rate / 1e12)
+                else:
+                    kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
+                                      gbs=rate / 1e9, frac_hbm=rate / 1e9 / PEAK_HBM_GBS)
+            if "embed" in kernels:
+                # SURVEY.md 8d counts 4616 B per token for the gather (a 2-byte activation row out); this kernel writes an
+                # f32 residual row (6152 B, the `gbs` above).  The fraction on SURVEY's own bytes:
+                w = 2.0 if args.weight_dtype == "f16" else 4.0
+                survey_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * w
+                ours_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * 4.0
+                kernels["embed"]["frac_hbm_survey_bytes"] = kernels["embed"]["frac_hbm"] * survey_b / ours_b
+            # PMC artefacts (separate rocprofv3 --pmc passes, diag/refresh_profiles.sh): used only when they were taken
+            # on THESE kernel sources - the files carry the tag and the source hash of their pass
+            sha = kernel_sources_sha16()
+            traffic, traffic_src, pmc = None, None, None
+            tpath, ppath = os.path.join(ROOT, "profiles", "gemm_traffic.json"), os.path.join(ROOT, "profiles", "gemm_pmc.json")
+            try:
+                tj = json.load(open(tpath))
+                traffic_src = tj.get("source")
+                if traffic_src and traffic_src.get("kernel_sha16") == sha:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            try:
+                pj = json.load(open(ppath))
+                if (pj.get("source") or {}).get("kernel_sha16") == sha:
+                    pmc = pj.get("gemm_f16s_kernel")
+            except Exception:
+                pass
+            avg_launch_s = gemm["ms"] / max(gemm["launches"], 1) * 1e-3
+            peak = PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3
+            roof = {"bound": "mfma", "kernel": "gemm_f16s_kernel" if args.weight_dtype == "f16" else "gemm_f32_kernel",
+                    "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
+                    "traffic": traffic,
+                    "traffic_source": traffic_src if traffic is not None else
+                    {"stale": True, "reason": "profiles/gemm_traffic.json was not taken on the current kernel sources",
+                     "file": traffic_src, "current_kernel_sha16": sha},
+                    "launches_per_step": gemm["launches"] // max(args.steps, 1),
+                    "avg_launch_ms": avg_launch_s * 1e3,
+                    # the same kernel against the OTHER roof: PMC bytes per launch / live launch time, over 8 TB/s.
+                    # The split-fp16 design moves 4 B per activation element between launches, so the MFMA-bound
+                    # kernel is also a heavy HBM client (DESIGN.md 4.1 "bytes")
+                    "hbm_gbs": traffic / avg_launch_s / 1e9 if traffic else None,
+                    "hbm_frac": traffic / avg_launch_s / (PEAK_HBM_GBS * 1e9) if traffic else None,
+                    "measured": "second pass of the same K steps with HIP events around every launch (profiler off in the timed region)",
+                    "note": "the GEMM launches also carry the LayerNorm work of the layer (LayerNorm fold: operand + row "
+                            "statistics in the producer epilogue, normalisation in the consumer epilogue); "
+                            "`unfused` = the same forward with separate LayerNorm launches (LTR_NO_LN_FOLD=1)",
+                    "unfused": unfused,
+                    # MFMA pipe utilisation / L2 hit rate of the kernel from the last PMC passes (profiles/gemm_pmc.json)
+                    "pmc": pmc}
         # steady rank step (nothing new to score): 37 B per request per step algorithmic
         rk_us = rank_ms[len(rank_ms) // 2] * 1e3
         kernels["rank_step"] = dict(us_per_step=rk_us, launches_per_step=2 if n_total <= 12288 else 9,
                                     gbs=37.0 * n_total / (rk_us * 1e-6) / 1e9,
                                     frac_hbm=37.0 * n_total / (rk_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                                     note="latency-bound: two dependent launches over a few hundred KB")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        pmc = None
-        ppath = os.path.join(ROOT, "profiles", "gemm_pmc.json")
-        if os.path.exists(ppath):
-            try:
-                pmc = json.load(open(ppath)).get("gemm_f16s_kernel")
-            except Exception:
-                pmc = None
         out = {
             "metric": "requests ranked/sec (cold call: OPT predictor forward + priority sort/aging)",
             "value": n_total * args.steps / elapsed,
             "unit": "requests/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "profiled_ms_per_step": prof_elapsed / args.steps * 1e3 if prof_elapsed else None,
             "p50_rank_latency_ms": step_ms[len(step_ms) // 2],
             "p50_steady_rank_latency_ms": rank_ms[len(rank_ms) // 2],
-            "p50_steady_new_latency_ms": steady_k_ms[len(steady_k_ms) // 2] if steady_k_ms else None,
-            "steady_new_requests": k_new,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # steady call with k new requests: score k + re-rank the whole queue (one GPU; SURVEY 8d "steady")
+            "p50_steady_new_latency_ms": steady or None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if args.weight_dtype == "f16" else "f32",
             "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths, random token ids)",
-            "config": {"workload": f"OPT-{args.model} predictor, {n_local} synthetic queue per GPU "
-                                   f"({n_total} total, {args.profile} length profile), cold ranker call",
+            "config": {"workload": (f"OPT-{args.model} predictor, fixed {n_total}-request synthetic queue ({args.profile} length "
+                                    f"profile), cold ranker call" if strong else
+                                    f"OPT-{args.model} predictor, {n_local} synthetic queue per GPU ({n_total} total, "
+                                    f"{args.profile} length profile), cold ranker call"),
                        "queue_per_gpu": n_local, "queue_total": n_total, "tokens_total": int(cu[-1]),
                        "tokens_rank0_shard": int(cu[my_r1] - cu[my_r0]), "starv": args.starv, "period": args.period,
                        "parallelism": f"request-sharded dp{world}" + (", token-balanced shards of one global queue, "
                                                                        "RCCL all-gather of scores" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16s_kernel" if args.weight_dtype == "f16" else "gemm_f32_kernel",
-                         "achieved": gemm_tflops, "peak": PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3,
-                         "unit": "TFLOP/s", "frac": gemm_tflops / (PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3),
-                         "traffic": traffic,
-                         "launches_per_step": gemm["launches"] // max(args.steps, 1),
-                         "avg_launch_ms": gemm["ms"] / max(gemm["launches"], 1),
-                         # the same kernel against the OTHER roof: PMC bytes per launch / live launch time, over 8 TB/s.
-                         # The split-fp16 design moves 4 B per activation element between launches, so the MFMA-bound
-                         # kernel is also a heavy HBM client (DESIGN.md 4.1 "bytes")
-                         "hbm_gbs": (traffic / (gemm["ms"] / max(gemm["launches"], 1) * 1e-3) / 1e9) if traffic else None,
-                         "hbm_frac": (traffic / (gemm["ms"] / max(gemm["launches"], 1) * 1e-3) / (PEAK_HBM_GBS * 1e9))
-                         if traffic else None,
-                         "note": "the GEMM launches also carry the LayerNorm work of the layer (LayerNorm fold: operand + row "
-                                 "statistics in the producer epilogue, normalisation in the consumer epilogue); "
-                                 "`unfused` = the same forward with separate LayerNorm launches (LTR_NO_LN_FOLD=1)",
-                         "unfused": unfused,
-                         # MFMA pipe utilisation / L2 hit rate of the kernel from the last PMC passes (profiles/gemm_pmc.json,
-                         # diag/refresh_profiles.sh); null when the file is absent
-                         "pmc": pmc},
+            "roofline": roof,
             "kernels": kernels,
+            "strong_scaling": strong_pt,
             "model_tflop_per_step": (lin + att) / 1e12,
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle)

@@ -8,9 +8,13 @@ mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles), cycles = GRBM_GUI_
 8 XCDs); 16 busy cycles per v_mfma_f32_16x16x32_f16.  Profiled passes clock ~3 % lower than plain runs (MI355X_MICROARCH.md,
 DVFS give-back), so the fraction is of the profiled launch."""
 import json
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_traffic import source_stamp  # noqa: E402
 
 
 def table(db):
@@ -39,6 +43,7 @@ def main():
                       wave_parked_frac=sq[k]["SQ_WAIT_ANY"] / sq[k]["SQ_WAVE_CYCLES"],
                       wave_issue_stall_frac=sq[k]["SQ_WAIT_INST_ANY"] / sq[k]["SQ_WAVE_CYCLES"],
                       l2_hit_rate=l2[k]["TCC_HIT_sum"] / (l2[k]["TCC_HIT_sum"] + l2[k]["TCC_MISS_sum"]))
+    res["source"] = source_stamp()
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -11,10 +11,24 @@ calibration measured on known-byte kernels in the library's own access forms.
 Both counters are in KiB.  factor[form] = known bytes / reported bytes; the guide's gfx950 rule (wide
 coalesced reads report 1/2) is what the dma / reg_x4 factors should reproduce.  Writes
 profiles/kernel_traffic.json (and keeps profiles/gemm_traffic.json, which bench.py reads, in sync)."""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_stamp():
+    """Which kernels the pass measured: LTR_PROFILE_TAG (refresh_profiles.sh's tag) + the hash of the kernel sources
+    (bench.py uses the numbers only while the hash still matches - same function there, kernel_sources_sha16)."""
+    h = hashlib.sha256()
+    for rel in ("vllm_ltr_amd/csrc/ltr_gemm.hip", "vllm_ltr_amd/csrc/ltr_api.hip"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return dict(tag=os.environ.get("LTR_PROFILE_TAG", ""), kernel_sha16=h.hexdigest()[:16])
 
 CALIB_BYTES = 4 << 30
 # which calibrated access form dominates each production kernel's reads
@@ -62,7 +76,8 @@ def main():
                           WRITE_SIZE_KiB_per_launch_raw=w_kib, read_factor=rf, write_factor=wf,
                           read_bytes_per_launch=f_kib * 1024.0 * rf, write_bytes_per_launch=w_kib * 1024.0 * wf,
                           hbm_bytes_per_launch=f_kib * 1024.0 * rf + w_kib * 1024.0 * wf)
-    out = dict(calibration=dict(bytes_per_kernel=CALIB_BYTES, factor=factors,
+    out = dict(source=source_stamp(),
+               calibration=dict(bytes_per_kernel=CALIB_BYTES, factor=factors,
                                 note="factor = known bytes / counter bytes on diag/pmc_calib.hip (4 GiB touched once "
                                      "per kernel, > Infinity Cache); fabric-side counters: Infinity-Cache hits are "
                                      "included, so production numbers are an upper bound on DRAM bytes"),
@@ -74,7 +89,7 @@ def main():
                        FETCH_SIZE_KiB_per_launch_raw=g["FETCH_SIZE_KiB_per_launch_raw"],
                        WRITE_SIZE_KiB_per_launch=g["WRITE_SIZE_KiB_per_launch_raw"],
                        fetch_correction=g["read_factor"], write_correction=g["write_factor"],
-                       hbm_bytes_per_launch=g["hbm_bytes_per_launch"],
+                       hbm_bytes_per_launch=g["hbm_bytes_per_launch"], source=source_stamp(),
                        note="see kernel_traffic.json; corrections measured by diag/pmc_calib.hip"),
                   open("profiles/gemm_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -150,3 +150,120 @@ def test_config4_shape_two_ranks_opt125m():
     for rank, ok, same, tok in res:
         assert ok and same, (rank, ok, same)
         assert abs(tok[0] - tok[1]) <= 2048          # token-balanced within one maximal request
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 at its size: OPT-125m, the 65,536-request / 5,734,532-token synthetic queue, sharded over
+# EIGHT ranks (processes sharing the one device of the box; gloo control plane), score all-gather.
+# ---------------------------------------------------------------------------------------------------------------
+def _worker_config4(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
+    import hashlib
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=40))
+    try:
+        from test_gpu_full_configs import _oracle_scores, _passes, _queue
+        from oracle import rank_step as rs
+        from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
+        from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+        from vllm_ltr_amd.rank import DeviceQueue
+        from vllm_ltr_amd.scorer import HipOPTScorer
+        dev = torch.device("cuda:0")
+        spec = OPTSpec.opt_125m()
+        ckpt = seeded_checkpoint(spec, 0)
+        sc = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
+        n = 65536
+        ids, cu, lens = _queue(spec, n, 64.0)                         # bench.py's generator, seed 0 (identical on every rank)
+        T = int(cu[-1])
+        ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+        queue = DeviceQueue(dev, starv=200, period=10, capacity=n)
+        queue.append(torch.zeros(n))
+        got = ShardedScorer(sc, dev, min_requests_to_shard=1024).score_device(ids_d, cu_d, cu, out=queue._score[:n])
+        assert got.data_ptr() == queue._score.data_ptr()               # gathered straight into the slot array
+        need = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        perm, n_sel, ran, _ = queue.step(need, torch.ones(n, dtype=torch.int32, device=dev), 2048, 256)
+        perm_h = perm.cpu().numpy()
+        digest = hashlib.sha256(perm_h.tobytes() + ran.cpu().numpy().tobytes()).hexdigest()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (digest, int(n_sel.item())))
+        same = all(x == gathered[0] for x in gathered)
+        bounds = shard_bounds(cu, world)
+        tok = [int(cu[y] - cu[x]) for x, y in bounds]
+        res = dict(rank=rank, same=same, T=T, tok=tok, n_sel=int(n_sel.item()))
+        if rank == 0:
+            scores = got.cpu().numpy()
+            single = sc.score_device(ids_d, cu_d, cu).cpu().numpy()   # what ONE process computes for the whole queue
+            res["bit_identical"] = bool(np.array_equal(scores, single))
+            # the oracle on the first and last request of every pass of every shard (+ a few random ones)
+            sample = set()
+            n_pass = 0
+            for r0, r1 in bounds:
+                cu_s = cu[r0:r1 + 1] - cu[r0]
+                for p0, p1 in _passes(cu_s, 196608):
+                    sample.update((r0 + p0, r0 + p1 - 1)); n_pass += 1
+            sample.update(np.random.RandomState(4).randint(0, n, 16).tolist())
+            sample = np.array(sorted(sample))
+            want = _oracle_scores(spec, ckpt, ids, cu, sample)
+            res["oracle_err"] = float(np.abs(want - scores[sample]).max())
+            res["oracle_n"], res["n_pass"] = int(len(sample)), n_pass
+            # the 64k permutation against the literal promote/demote + stable sort of the oracle
+            z = np.zeros(n, np.int32)
+            res["perm_ok"] = bool(np.array_equal(perm_h, rs.rank_step_np(scores, z.copy(), z.copy(), z.copy(), 200, 10)))
+            wn, _ = rs.budget_walk(lens[perm_h], np.ones(n, np.int32), 2048, 256)
+            res["budget_ok"] = wn == int(n_sel.item())
+        dist.barrier()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_opt125m_64k_queue_sharded_over_8_ranks_full_size():
+    """BASELINE config 4 at FULL size on one device: 65,536 requests / 5,734,532 tokens through ShardedScorer with 8
+    ranks (LTR_TEST_CONFIG4_WORLD overrides): gathered scores bit-identical to the single-process call, an oracle sample
+    (1e-4) with the first and last request of every pass of every shard, the same 64k permutation + budget selection on
+    every rank, equal to the oracle's literal sort."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    world = int(os.environ.get("LTR_TEST_CONFIG4_WORLD", "8"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=2400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r["rank"])
+    r0 = res[0]
+    assert r0["T"] == 5734532                                        # the 64k queue of bench.py (seed 0)
+    assert all(r["same"] for r in res), "ranks disagree on the permutation / selection"
+    assert r0["bit_identical"], "gathered scores differ from the single-process scores"
+    print(f"config 4 (OPT-125m, 65536 requests, {r0['T']} tokens, {world} ranks x {r0['n_pass'] // world} passes): oracle "
+          f"sample of {r0['oracle_n']} requests, max|d| = {r0['oracle_err']:.3e}; shard tokens {r0['tok']}")
+    assert r0["oracle_n"] >= 64 and r0["oracle_err"] <= 1e-4
+    assert r0["perm_ok"] and r0["budget_ok"]
+    assert max(r0["tok"]) - min(r0["tok"]) <= 2048                   # token-balanced within one maximal request
+
+
+def test_bench_strong_scaling_mode_two_ranks_one_device():
+    """`bench.py --queue-total` (fixed queue, strong scaling) through torch.distributed.run with two ranks on the one
+    device (gloo): the line says strong, carries the queue it was given, and two ranks finish the 4,096-request queue."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LTR_BENCH_ONE_DEVICE="1", LTR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--queue-total", "4096", "--no-cpu-baseline", "--no-unfused", "--steady-new", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["queue_total"] == 4096
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["p50_steady_new_latency_ms"]["16"] > 0
+    assert 0 < out["config"]["tokens_rank0_shard"] < out["config"]["tokens_total"]

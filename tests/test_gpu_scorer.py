@@ -644,3 +644,48 @@ def test_layernorm_fold_on_and_off_agree(dev, monkeypatch):
     plain.profile(True); plain.profile_read(True); plain.score(ids, cu)
     # + 1: the LayerNorm of the n_req last-token rows in front of the last layer's Q GEMM (last-query pruning)
     assert folded.profile_read()["ln"]["launches"] == 2 and plain.profile_read()["ln"]["launches"] == 2 * spec.num_hidden_layers + 1
+
+
+@pytest.mark.parametrize("kind", ["burst", "gamma"])
+def test_config5_ranker_side_trace_replay(dev, kind):
+    """BASELINE config 5, the ranker's share: a burst (everything at t = 0, benchmarks/burst-*.sh) and a gamma arrival
+    process (benchmark_serving_real.py:159-176) replayed through MI355XRanker.install() on an (unpatched) scheduler
+    loop - per step k arrivals -> obtain_aux_scores(k) + order + aging.  EVERY step's order is compared with the
+    literal reference expressions (promote/demote + stable sorted, scheduler.py:984-998; aging :1358-1365) replayed
+    on the same deques; every request finishes; latency percentiles come out of the summary."""
+    from oracle import rank_step as rs
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
+    spec = OPTSpec.tiny_pre_ln()
+    sc = _scorer(spec, seeded_checkpoint(spec, 4), dev, "f16")
+    ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=150)
+    reqs = synthetic_trace(spec.vocab_size, 400, kind, request_rate=200.0, cv=2.0, seed=1, prompt_median=24.0,
+                           output_median=12.0, max_prompt=140)
+    mirror, state = {}, {}
+
+    def before(step, s):
+        state["concat"] = list(s.waiting) + list(s.running) + list(s.swapped)
+
+    def after(step, s, ran):
+        concat = state["concat"]
+        for g in concat:
+            mirror.setdefault(g.request_id, rs.Req(g.request_id, g.aux_model_score))
+        lit = rs.opt_order([mirror[g.request_id] for g in concat], 20, 3)
+        assert [g.request_id for g in s.last_order] == [m.request_id for m in lit], step
+        ran_ids = {g.request_id for g in ran}
+        all_pri = list(s.swapped) + list(s.running) + list(s.waiting)
+        rs.age_update([mirror[g.request_id] for g in all_pri], [mirror[g.request_id] for g in all_pri if g.request_id in ran_ids])
+        state["promoted"] = state.get("promoted", 0) + sum(m.pri == -1 for m in lit)
+
+    res = replay(ranker, reqs, backbone_ms=5.0, max_num_batched_tokens=256, max_num_seqs=16, before_step=before, on_step=after)
+    s = summarize(res)
+    print(f"{kind}: {s['steps']} steps, max queue {s['max_queue']}, ranker p50/p95/p99 = {s['ranker_ms_all']['p50']:.3f} / "
+          f"{s['ranker_ms_all']['p95']:.3f} / {s['ranker_ms_all']['p99']:.3f} ms, ranker share of HOL {s['ranker_share_of_hol']:.3f}")
+    assert s["finished"] == 400 and all(r.aux_model_score is not None for r in reqs)
+    assert ranker.stats["requests_scored"] == 400              # every request scored exactly once
+    assert state["promoted"] > 0                               # starvation promotions happened and matched
+    if kind == "burst":
+        assert s["ranker_ms_with_arrivals"]["n"] == 1          # one cold call for the whole burst
+    else:
+        assert s["ranker_ms_with_arrivals"]["n"] > 20
+    assert s["ranker_ms_steady"]["p50"] < 5.0

@@ -142,10 +142,14 @@ def test_gradient_only_calls_do_not_advance_adam_and_bad_class_labels_raise():
     a.step(*args, apply_update=False)
     la = a.step(*args)
     lb = b.step(*args)
-    assert la == lb
-    sa, sb = a.state(), b.state()
+    assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+    sa, sb, s0 = a.state(), b.state(), HipPredictorTrainer(spec, ckpt, "cuda:0", lr=lr, weight_decay=wd, loss=loss_name).state()
     for k in sb:
-        assert np.array_equal(sa[k], sb[k]), k
+        # the same first Adam step (t = 1) on both: a bias correction taken at t = 3 would shrink every displacement by
+        # ~36 % (m_hat / sqrt(v_hat) = 0.64 instead of 1).  Not bit-equal: the embedding gradients are atomic sums.
+        moved = np.abs(sb[k] - s0[k]).max()
+        assert np.abs(sa[k] - sb[k]).max() <= 0.02 * lr + 1e-9, k
+        assert moved == 0 or moved > 0.5 * lr, k
     zc, cspec, _, clr, cwd, _ = _load("pre_ln_class5_ce")
     c = HipPredictorTrainer(cspec, seeded_checkpoint(cspec, int(zc["seed"])), "cuda:0", lr=clr, weight_decay=cwd,
                             loss="crossentropy")
