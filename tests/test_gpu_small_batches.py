@@ -1,0 +1,86 @@
+"""-m gpu: the small-batch scoring path (SURVEY.md 8d "steady" call: k new requests scored + the queue re-ranked).
+
+Batches of a few hundred to a few thousand tokens run the GEMMs on the small-tile / mid-tile deep-ring kernels
+(ltr_gemm.hip `gemm_f16s_small_kernel`, selected by row count inside launch_gemm).  Those kernels keep the large-tile
+kernel's arithmetic - same MFMA, lo pass then hi pass per 32-wide K-slab, slabs in order, same epilogue expressions -
+so a request's score must not depend on the batch it arrives in: BIT-IDENTICAL whether it is scored alone (small
+kernel), with 15 others, with ~100 others (mid kernel) or inside a queue of several hundred (large-tile kernel), and
+within the north_star tolerance of the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.opt_scorer import OracleOPTScorer
+from util import bench_lengths, synthetic_batch
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _sub(ids, cu, idx):
+    lens = np.diff(cu)[idx]
+    ids_s = np.concatenate([ids[cu[i]:cu[i + 1]] for i in idx])
+    return ids_s, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("model", ["125m", "350m", "tiny_pre_ln", "tiny_post_ln"])
+def test_scores_do_not_depend_on_the_batch_size_regime(model):
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = {"125m": OPTSpec.opt_125m, "350m": OPTSpec.opt_350m, "tiny_pre_ln": OPTSpec.tiny_pre_ln,
+            "tiny_post_ln": OPTSpec.tiny_post_ln}[model]()
+    ckpt = seeded_checkpoint(spec, 11)
+    sc = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
+    tiny = model.startswith("tiny")
+    n = 420
+    lens = bench_lengths(n, seed=3, mu=24.0 if tiny else 64.0).clip(1, 150 if tiny else 1024)
+    lens[5], lens[6] = 1, 2                                       # shortest prompts
+    lens[7] = 150 if tiny else 1024                               # a maximal one
+    ids, cu = synthetic_batch(spec, lens.tolist(), 5)
+    T = int(cu[-1])
+    assert T > 3072                                               # the whole queue: the 128 x 256 kernel
+    whole = sc.score(ids, cu)
+    assert np.isfinite(whole).all()
+    seen = {}
+    for group in ([0], [5], [6], [7], list(range(8, 24)), list(range(30, 94)), list(range(100, 260))):
+        got = sc.score(*_sub(ids, cu, group))
+        t = int(np.diff(cu)[group].sum())
+        seen[len(group)] = t
+        assert np.array_equal(got, whole[group]), (model, len(group), t, np.abs(got - whole[group]).max())
+    print(f"{model}: batches of {seen} tokens score bit-identically to the {T}-token queue")
+    if model in ("125m", "tiny_pre_ln", "tiny_post_ln"):
+        idx = [0, 5, 6, 7, 8, 9]
+        want = OracleOPTScorer(spec, ckpt).score(*_sub(ids, cu, idx))
+        assert np.abs(want - whole[idx]).max() <= TOL
+
+
+def test_single_request_latency_budget():
+    """One arrival scored and the 8k queue re-ranked: the call a live scheduler step makes.  The 128 x 256 kernel needed
+    2.1 ms for it (49 GEMM launches of 37 us on a dozen CUs); the bound here is loose (boxes differ), the number is
+    printed."""
+    from vllm_ltr_amd.rank import DeviceQueue
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.opt_125m()
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
+    dev = torch.device("cuda:0")
+    n = 8192
+    queue = DeviceQueue(dev, starv=200, period=10, capacity=n)
+    queue.append(torch.randn(n))
+    need = torch.full((n,), 64, dtype=torch.int32, device=dev)
+    ones = torch.ones(n, dtype=torch.int32, device=dev)
+    out = {}
+    for k in (1, 16, 64):
+        lens = bench_lengths(k, seed=0)
+        ids, cu = synthetic_batch(spec, lens.tolist(), 1)
+        ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(14)]
+        for a, b in ev:
+            a.record()
+            sc.score_device(ids_d, cu_d, cu, out=queue._score[:k])
+            queue.step(need, ones, 2048, 256)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev[3:])
+        out[k] = ms[len(ms) // 2]
+    print("steady call latency (k new requests + re-rank of the 8k queue), ms:", {k: round(v, 3) for k, v in out.items()})
+    assert out[1] < 1.5 and out[16] < 2.2 and out[64] < 3.5

@@ -187,6 +187,87 @@ __device__ unsigned long long g_waits[8192 * 2];
 constexpr float LN_FOLD_SCALE = 16.f;
 enum { LN_NONE = 0, LNP = 1, LNC = 2 };
 
+// One (row, 8 columns) piece of the epilogue, shared by the large-tile and the small-tile kernel: x = accumulator
+// columns ccol..ccol+3 (va) and ccol_b..ccol_b+3 (vb) of row `grow`; LayerNorm-fold consumer scaling, bias, ReLU,
+// residual, f32 / split stores, LayerNorm-fold producer outputs.  The 8 lanes that hold one row's 64-column piece are
+// consecutive lanes of one wave (lane & 7 = position in the piece); `piece64` = index of that piece in the row.
+template <int LNM>
+__device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, float4 vb, const float4& ra, const float4& rb,
+                                               const float4& bias_a, const float4& bias_b, const float4& lnv_a,
+                                               const float4& lnv_b, const float2 st2, int grow, int ccol, int ccol_b,
+                                               size_t o, int M, int lane, int piece64) {
+  if (LNM == LNC) {   // v = (acc - mean c_n) rstd / scale (+ d_n, held in bias)
+    va.x = (va.x - st2.x * lnv_a.x) * st2.y; va.y = (va.y - st2.x * lnv_a.y) * st2.y;
+    va.z = (va.z - st2.x * lnv_a.z) * st2.y; va.w = (va.w - st2.x * lnv_a.w) * st2.y;
+    vb.x = (vb.x - st2.x * lnv_b.x) * st2.y; vb.y = (vb.y - st2.x * lnv_b.y) * st2.y;
+    vb.z = (vb.z - st2.x * lnv_b.z) * st2.y; vb.w = (vb.w - st2.x * lnv_b.w) * st2.y;
+  }
+  float x[8] = {va.x + bias_a.x, va.y + bias_a.y, va.z + bias_a.z, va.w + bias_a.w,
+                vb.x + bias_b.x, vb.y + bias_b.y, vb.z + bias_b.z, vb.w + bias_b.w};
+  if (ep.relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+  }
+  x[0] += ra.x; x[1] += ra.y; x[2] += ra.z; x[3] += ra.w;
+  x[4] += rb.x; x[5] += rb.y; x[6] += rb.z; x[7] += rb.w;
+  if (ep.out_f32) {
+    epi_store16(ep.out_f32 + o, x);
+    epi_store16(ep.out_f32 + o + (ccol_b - ccol), x + 4);
+  }
+  if (ep.out_hi) {
+    __half h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
+    const size_t os = ep.out_slab ? slab_off(grow, ccol, M) : o;
+#ifdef LTR_GEMM_NOSTORE   // diag: epilogue without its global stores (keeps the values alive through a never-true branch)
+    if (h[0] == __half(12345.f) && l[7] == __half(54321.f))
+#endif
+    {
+      epi_store16((__half*)ep.out_hi + os, h);
+      epi_store16((__half*)ep.out_lo + os, l);
+    }
+  }
+  if (LNM == LNP) {
+    // x[0..7] = columns ccol..+3 and ccol+32..+35 of the f32 row just stored (wide ownership: the 8 lanes of a
+    // row hold its 64 columns in this wave).  Operand of the next GEMM: split(x gamma scale), slab-major -
+    // per plane the 8 lanes x 8 rows of one store instruction cover 512 contiguous bytes of a slab.
+    const float gs[8] = {lnv_a.x, lnv_a.y, lnv_a.z, lnv_a.w, lnv_b.x, lnv_b.y, lnv_b.z, lnv_b.w};
+    __half h[8], l[8];
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float xs = x[e] * gs[e]; amax = fmaxf(amax, fabsf(xs)); split_f16(xs, h[e], l[e]); }
+    // The operand carries the UN-normalised residual stream (times gamma, times 16): beyond fp16's 65504 its hi
+    // plane is inf and the scores NaN, where separate LayerNorm launches would still work.  Flag it (NaN fails
+    // the comparison too and is flagged).
+    if (!(amax <= 65504.f) && ep.err_flag) atomicOr(ep.err_flag, 2);
+    // lane pair (l, l ^ 1) holds columns {4k..4k+3, 32+4k..} and {4k+4..4k+7, 36+4k..}: swap halves so that the even
+    // lane owns 8 consecutive columns of the first slab and the odd lane 8 of the second -> ONE 16-byte store
+    // per plane and lane (8-byte stores issue at half the rate per byte)
+    const bool odd = lane & 1;
+    uint2 hk = *reinterpret_cast<const uint2*>(odd ? h + 4 : h), hs = *reinterpret_cast<const uint2*>(odd ? h : h + 4);
+    uint2 lk = *reinterpret_cast<const uint2*>(odd ? l + 4 : l), ls = *reinterpret_cast<const uint2*>(odd ? l : l + 4);
+    uint2 hr, lr;   // what the partner sends: its half that belongs to my slab
+    hr.x = __shfl_xor(hs.x, 1, 64); hr.y = __shfl_xor(hs.y, 1, 64);
+    lr.x = __shfl_xor(ls.x, 1, 64); lr.y = __shfl_xor(ls.y, 1, 64);
+    const uint4 hv = odd ? make_uint4(hr.x, hr.y, hk.x, hk.y) : make_uint4(hk.x, hk.y, hr.x, hr.y);
+    const uint4 lv = odd ? make_uint4(lr.x, lr.y, lk.x, lk.y) : make_uint4(lk.x, lk.y, lr.x, lr.y);
+    const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
+    const size_t oo = slab_off(grow, c0, M);
+    epi_store16((__half*)ep.ln_hi + oo, &hv);
+    epi_store16((__half*)ep.ln_lo + oo, &lv);
+    // (mean, M2) of this 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
+    // row, so they are active exactly when this lane is)
+    float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    const float mu = sm * (1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float dd = x[e] - mu; q = fmaf(dd, dd, q); }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    if ((lane & 7) == 0) ep.stats_out[(size_t)piece64 * M + grow] = make_float2(mu, q);
+  }
+}
+
 template <int LNM>
 __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
@@ -380,77 +461,10 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         if (!ok[it]) continue;
-        if (LNM == LNC) {   // v = (acc - mean c_n) rstd / scale (+ d_n, held in bias)
-          const float2 st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
-          va[it].x = (va[it].x - st2.x * lnv_a.x) * st2.y; va[it].y = (va[it].y - st2.x * lnv_a.y) * st2.y;
-          va[it].z = (va[it].z - st2.x * lnv_a.z) * st2.y; va[it].w = (va[it].w - st2.x * lnv_a.w) * st2.y;
-          vb[it].x = (vb[it].x - st2.x * lnv_b.x) * st2.y; vb[it].y = (vb[it].y - st2.x * lnv_b.y) * st2.y;
-          vb[it].z = (vb[it].z - st2.x * lnv_b.z) * st2.y; vb[it].w = (vb[it].w - st2.x * lnv_b.w) * st2.y;
-        }
-        float x[8] = {va[it].x + bias_a.x, va[it].y + bias_a.y, va[it].z + bias_a.z, va[it].w + bias_a.w,
-                      vb[it].x + bias_b.x, vb[it].y + bias_b.y, vb[it].z + bias_b.z, vb[it].w + bias_b.w};
-        if (ep.relu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
-        }
-        x[0] += ra[it].x; x[1] += ra[it].y; x[2] += ra[it].z; x[3] += ra[it].w;
-        x[4] += rb[it].x; x[5] += rb[it].y; x[6] += rb[it].z; x[7] += rb[it].w;
-        if (ep.out_f32) {
-          epi_store16(ep.out_f32 + o[it], x);
-          epi_store16(ep.out_f32 + o[it] + (ecol_b - ecol), x + 4);
-        }
-        if (ep.out_hi) {
-          __half h[8], l[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
-          const size_t os = ep.out_slab ? slab_off(gr[it], ccol, M) : o[it];
-#ifdef LTR_GEMM_NOSTORE   // diag: epilogue without its global stores (keeps the values alive through a never-true branch)
-          if (h[0] == __half(12345.f) && l[7] == __half(54321.f))
-#endif
-          {
-            epi_store16((__half*)ep.out_hi + os, h);
-            epi_store16((__half*)ep.out_lo + os, l);
-          }
-        }
-        if (LNM == LNP) {
-          // x[0..7] = columns ccol..+3 and ccol+32..+35 of the f32 row just stored (wide ownership: the 8 lanes of a
-          // row hold its 64 columns in this wave).  Operand of the next GEMM: split(x gamma scale), slab-major -
-          // per plane the 8 lanes x 8 rows of one store instruction cover 512 contiguous bytes of a slab.
-          const float gs[8] = {lnv_a.x, lnv_a.y, lnv_a.z, lnv_a.w, lnv_b.x, lnv_b.y, lnv_b.z, lnv_b.w};
-          __half h[8], l[8];
-          float amax = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float xs = x[e] * gs[e]; amax = fmaxf(amax, fabsf(xs)); split_f16(xs, h[e], l[e]); }
-          // The operand carries the UN-normalised residual stream (times gamma, times 16): beyond fp16's 65504 its hi
-          // plane is inf and the scores NaN, where separate LayerNorm launches would still work.  Flag it (NaN fails
-          // the comparison too and is flagged).
-          if (!(amax <= 65504.f) && ep.err_flag) atomicOr(ep.err_flag, 2);
-          // lane pair (l, l ^ 1) holds columns {4k..4k+3, 32+4k..} and {4k+4..4k+7, 36+4k..}: swap halves so that the even
-          // lane owns 8 consecutive columns of the first slab and the odd lane 8 of the second -> ONE 16-byte store
-          // per plane and lane (8-byte stores issue at half the rate per byte)
-          const bool odd = lane & 1;
-          uint2 hk = *reinterpret_cast<const uint2*>(odd ? h + 4 : h), hs = *reinterpret_cast<const uint2*>(odd ? h : h + 4);
-          uint2 lk = *reinterpret_cast<const uint2*>(odd ? l + 4 : l), ls = *reinterpret_cast<const uint2*>(odd ? l : l + 4);
-          uint2 hr, lr;   // what the partner sends: its half that belongs to my slab
-          hr.x = __shfl_xor(hs.x, 1, 64); hr.y = __shfl_xor(hs.y, 1, 64);
-          lr.x = __shfl_xor(ls.x, 1, 64); lr.y = __shfl_xor(ls.y, 1, 64);
-          const uint4 hv = odd ? make_uint4(hr.x, hr.y, hk.x, hk.y) : make_uint4(hk.x, hk.y, hr.x, hr.y);
-          const uint4 lv = odd ? make_uint4(lr.x, lr.y, lk.x, lk.y) : make_uint4(lk.x, lk.y, lr.x, lr.y);
-          const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
-          const size_t oo = slab_off(gr[it], c0, M);
-          epi_store16((__half*)ep.ln_hi + oo, &hv);
-          epi_store16((__half*)ep.ln_lo + oo, &lv);
-          // (mean, M2) of this wave's 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
-          // row, so they are active exactly when this lane is)
-          float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-          sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
-          const float mu = sm * (1.f / 64.f);
-          float q = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float dd = x[e] - mu; q = fmaf(dd, dd, q); }
-          q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-          if ((lane & 7) == 0) ep.stats_out[(size_t)(tn * 4 + wc) * M + gr[it]] = make_float2(mu, q);
-        }
+        float2 st2 = make_float2(0.f, 0.f);
+        if (LNM == LNC) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
+        epilogue_piece<LNM>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, gr[it], ccol, ccol_b,
+                            o[it], M, lane, tn * 4 + wc);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -468,6 +482,220 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     g_waits[blockIdx.x * 2] = tl_dma; g_waits[blockIdx.x * 2 + 1] = tl_bar;
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------
+// F16 split mode, SMALL batches (the steady scheduler step: a handful of arrivals to score, SURVEY.md 8d "steady").
+// With M of a few hundred rows the 128 x 256 kernel has 3-12 workgroups, each walking its K-slabs behind a
+// two-stage ring at one DMA round trip per slab: 37 us per launch, 49 launches per scored request (2.1 ms for ONE
+// 86-token prompt, profiles/r02_ab_gemm_probes.txt section 5).  This variant spends the chip differently:
+//  * small tiles (BM x BN = 32 x 64 with 4 waves, or 64 x 128 with 8) so that a 1-request batch still makes 36-144
+//    workgroups and a 16-request batch fills every CU;
+//  * 64-wide K stages in a RING OF FOUR (three stages in flight per workgroup, counted vmcnt, one raw barrier per
+//    stage) - latency-bound, so what matters is bytes in flight per CU, not bytes per FLOP;
+//  * the same fragment layout, the same MFMA (lo pass then hi pass per 32-wide slab, slabs in order) and the same
+//    epilogue arithmetic as the large-tile kernel: results are BIT-IDENTICAL to it, so a request's score does not
+//    depend on which kernel a batch size selects (tests/test_gpu_small_batches.py).
+// ------------------------------------------------------------------------------------
+constexpr int SKS = 64;          // K per stage = two 32-wide slabs
+template <int BM_, int BN_, int SSTAGES> struct SmallCfg {
+  static constexpr int WM = 2, WN = BN_ / 32;                       // 32 x 64 -> 2 x 2 waves (16 x 32 each); 64 x 128 -> 2 x 4 (32 x 32)
+  static constexpr int NW = WM * WN;
+  static constexpr int TI = BM_ / WM / 16, TJ = BN_ / WN / 16;      // MFMA blocks per wave
+  static constexpr int PA = BM_ / 16 * 2, PW = BN_ / 16;            // 1-KiB DMA pieces per 32-wide slab: A hi|lo, W
+  static constexpr int SUB = (PA + PW) * 512;                       // halves per 32-wide slab image
+  static constexpr int STAGE_H = 2 * SUB;                           // halves per stage
+  static constexpr int PIECES = 2 * (PA + PW) / NW;                 // DMA instructions per wave and stage
+  static constexpr int CLDS = BN_ + 4;                              // f32 row stride of the epilogue tile
+  static constexpr size_t LDS_BYTES = (size_t)SSTAGES * STAGE_H * 2 + BM_ * 8;
+  static_assert(2 * (PA + PW) % NW == 0 && PIECES == 4, "piece map assumes 4 DMA instructions per wave and stage");
+  static_assert(SSTAGES >= 3 && SSTAGES <= 8, "counted vmcnt waits cover up to 6 stages in flight");
+  static_assert((size_t)BM_ * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2, "epilogue tile must fit the ring");
+};
+
+// Workgroup -> tile map of the small-tile kernels: the 8 XCDs (block b runs on XCD b % 8, private 4 MiB L2s) form an
+// RX x CX grid, XCD (i, j) owns row range i and column range j of the tile grid and walks it N fastest.  A weight matrix
+// is 1.2-4.7 MB: with CX column ranges an XCD keeps only its 1 / CX of it resident, while the activation rows stream
+// through once per XCD column (fabric traffic CX * A + RX * W instead of 8 * W with every XCD thrashing its L2 on the
+// whole matrix).  Blocks past an XCD's own tile count exit (the grid is 8 * the largest count).
+struct XcdMap { int rx, cx, per_xcd; };
+__host__ __device__ __forceinline__ void xcd_range(int n, int parts, int i, int& lo, int& cnt) {
+  const int q = n / parts, r = n % parts;
+  lo = i * q + min(i, r);
+  cnt = q + (i < r ? 1 : 0);
+}
+__device__ __forceinline__ bool xcd_tile(int bid, int tiles_m, int tiles_n, XcdMap mp, int& tm, int& tn) {
+  const int x = bid % NXCD, l = bid / NXCD;
+  const int xi = x / mp.cx, xj = x % mp.cx;
+  int r0, nr, c0, nc;
+  xcd_range(tiles_m, mp.rx, xi, r0, nr);
+  xcd_range(tiles_n, mp.cx, xj, c0, nc);
+  if (l >= nr * nc) return false;
+  tm = r0 + l / nc;
+  tn = c0 + l % nc;
+  return true;
+}
+
+template <int LNM, int BM_, int BN_, int SSTAGES>
+__global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f16s_small_kernel(
+    const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
+    int K, int tiles_m, int tiles_n, XcdMap xmap, Epilogue ep) {
+  using C = SmallCfg<BM_, BN_, SSTAGES>;
+  // dynamic LDS on purpose: with a static array hipcc tracks the LDS-DMA stores against every ds_read and drains
+  // vmcnt(0) in front of the first fragment read of each stage (ltr_attn.hip has the same note)
+  extern __shared__ __attribute__((aligned(16))) __half smem[];
+  float2* s_stat = reinterpret_cast<float2*>(smem + SSTAGES * C::STAGE_H);
+  int tm, tn;
+  if (!xcd_tile(blockIdx.x, tiles_m, tiles_n, xmap, tm, tn)) return;
+  const int m0 = tm * BM_, n0 = tn * BN_;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / C::WN, wc = wave % C::WN;
+
+  // this wave's four DMA pieces of a stage: piece q = wave * 4 + p of the stage's 2 x (PA + PW); slab q / (PA + PW),
+  // then r = q % (PA + PW): A hi groups, A lo groups, W groups - the LDS image of a slab is exactly r * 1 KiB
+  const __half* gsrc[4];
+  size_t gstep[4];      // source advance per 32-wide slab
+  int ldst[4];          // halves from the stage base
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = wave * 4 + p, sl = q / (C::PA + C::PW), r = q % (C::PA + C::PW);
+    const int row16 = lane >> 2, c_log = (lane & 3) ^ swz(row16);
+    ldst[p] = sl * C::SUB + r * 512;
+    if (r < C::PA) {
+      const int g = r % (C::PA / 2);
+      const int row = min(m0 + g * 16 + row16, M - 1);
+      gstep[p] = ep.a_slab ? (size_t)M * BK16 : (size_t)BK16;
+      gsrc[p] = (r < C::PA / 2 ? a_hi : a_lo) + (size_t)row * (ep.a_slab ? BK16 : K) + c_log * 8 + sl * gstep[p];
+    } else {
+      const int g = r - C::PA;
+      const int row = min(n0 + g * 16 + row16, N - 1);
+      gstep[p] = (size_t)N * BK16;
+      gsrc[p] = w + (size_t)row * BK16 + c_log * 8 + sl * gstep[p];
+    }
+  }
+  auto issue = [&](int slot, int kt) {
+    __half* base = smem + slot * C::STAGE_H;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gsrc[p] + (size_t)(2 * kt) * gstep[p]), (lds_void*)(base + ldst[p]), 16, 0, 0);
+  };
+
+  f32x4 acc[C::TI][C::TJ];
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fk = lane >> 4;
+  const int nst = K / SKS;
+#pragma unroll
+  for (int st = 0; st < SSTAGES - 1; ++st)
+    if (st < nst) issue(st, st);
+  if (LNM == LNC && tid < BM_) {     // (mean, M2) pieces of the row -> (mean, rstd / scale); see the large-tile kernel
+    const int row = min(m0 + tid, M - 1);
+    const float2* sp = ep.stats_in + row;
+    const float2 s0 = sp[0];
+    float s1 = 0.f, s2 = 0.f, sm = s0.y;
+#pragma unroll 4
+    for (int p = 1; p < ep.n_part; ++p) { const float2 v = sp[(size_t)p * M]; const float d = v.x - s0.x; s1 += d; s2 = fmaf(d, d, s2); sm += v.y; }
+    const float np_ = (float)ep.n_part;
+    const float mean = s0.x + s1 / np_;
+    const float m2 = sm + 64.f * fmaxf(s2 - s1 * s1 / np_, 0.f);
+    s_stat[tid] = make_float2(mean, rsqrtf(m2 / (64.f * np_) + LN_EPS) * (1.f / LN_FOLD_SCALE));
+  }
+  for (int kt = 0; kt < nst; ++kt) {
+    // stage kt has landed once at most the younger stages' pieces (4 per stage and wave) are outstanding
+    const int ahead = min(SSTAGES - 2, nst - 1 - kt);
+    switch (ahead) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();                       // everyone's pieces of stage kt landed; stage kt-1 fully consumed
+    if (kt + SSTAGES - 1 < nst) issue((kt + SSTAGES - 1) % SSTAGES, kt + SSTAGES - 1);
+    const __half* sb = smem + (kt % SSTAGES) * C::STAGE_H;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const __half* s_ahi = sb + sl * C::SUB;
+      const __half* s_alo = s_ahi + BM_ * BK16;
+      const __half* s_w = s_ahi + 2 * BM_ * BK16;
+      f16x8 ah[C::TI], al[C::TI], bw[C::TJ];
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i) {
+        const int row = wr * (C::TI * 16) + i * 16 + frow;
+        ah[i] = *reinterpret_cast<const f16x8*>(s_ahi + lds_off_h(row, fk));
+        al[i] = *reinterpret_cast<const f16x8*>(s_alo + lds_off_h(row, fk));
+      }
+#pragma unroll
+      for (int j = 0; j < C::TJ; ++j) {
+        const int col = wc * (C::TJ * 16) + j * 16 + frow;
+        bw[j] = *reinterpret_cast<const f16x8*>(s_w + lds_off_h(col, fk));
+      }
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---- epilogue: the whole BM x BN tile through LDS (the ring is idle), then one (row, 8 columns) piece per lane
+  __syncthreads();
+  float* s_c = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        s_c[(wr * (C::TI * 16) + i * 16 + 4 * (lane >> 4) + e) * C::CLDS + wc * (C::TJ * 16) + j * 16 + (lane & 15)] = acc[i][j][e];
+  __syncthreads();
+  // one (row, 8 columns) piece per lane and pass.  (Fetching the bias / LayerNorm-fold vectors / residual row of the
+  // piece BEFORE the K loop, to take them off the tail of the launch, was measured and is slower: 830 vs 726 us for a
+  // one-request call - the early loads sit in front of the first operand pieces.)
+  const bool wide = ep.out_hi == nullptr;
+  const int l8 = lane & 7;
+  const int ecol = l8 * (wide ? 4 : 8), ecol_b = wide ? ecol + 32 : ecol + 4;
+  constexpr int P64 = BN_ / 64;                                      // 64-column pieces per tile row
+#pragma unroll
+  for (int pi = 0; pi < BM_ * BN_ / 8 / (C::NW * 64); ++pi) {
+    const int idx = (pi * (C::NW * 64) + tid) >> 3;                  // (row, piece) index; the 8 lanes of a piece are consecutive
+    const int srow = idx / P64, pc = idx % P64;
+    const int grow = m0 + srow;
+    const int ccol = n0 + pc * 64 + ecol, ccol_b = n0 + pc * 64 + ecol_b;
+    if (grow >= M || ccol >= N) continue;
+    const float4 va = *reinterpret_cast<const float4*>(s_c + srow * C::CLDS + pc * 64 + ecol);
+    const float4 vb = *reinterpret_cast<const float4*>(s_c + srow * C::CLDS + pc * 64 + ecol_b);
+    const size_t o = (size_t)grow * N + ccol;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    if (ep.resid) {
+      ra = *reinterpret_cast<const float4*>(ep.resid + o);
+      rb = *reinterpret_cast<const float4*>(ep.resid + o + (ecol_b - ecol));
+    }
+    float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
+    if (ep.bias) {
+      bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
+      bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
+    }
+    float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;    // LNP: gamma * scale; LNC: c_n
+    if (LNM != LN_NONE) {
+      const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
+      lnv_a = *reinterpret_cast<const float4*>(src + ccol);
+      lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
+      if (LNM == LNP) {
+        lnv_a.x *= LN_FOLD_SCALE; lnv_a.y *= LN_FOLD_SCALE; lnv_a.z *= LN_FOLD_SCALE; lnv_a.w *= LN_FOLD_SCALE;
+        lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
+      }
+    }
+    float2 st2 = make_float2(0.f, 0.f);
+    if (LNM == LNC) st2 = s_stat[srow];
+    epilogue_piece<LNM>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, grow, ccol, ccol_b, o, M, lane, tn * P64 + pc);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -643,6 +871,58 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     static const int gm_wide = [] { const char* e = getenv("LTR_GEMM_GM"); return e ? atoi(e) : GM_DEFAULT; }();
     static const int gm_narrow = [] { const char* e = getenv("LTR_GEMM_GM_NARROW"); return e ? atoi(e) : (GM_DEFAULT | 65536); }();
     const int gm = tiles_n <= 4 ? gm_narrow : gm_wide;
+    // Small batches (a scheduler step with a few arrivals): the small-tile, deep-ring kernels (bit-identical results).
+    // LTR_GEMM_SMALL_M / LTR_GEMM_MID_M: row thresholds (0 switches a variant off; A/B knobs).
+    static const int small_m = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 1024; }();
+    static const int mid_m = [] { const char* e = getenv("LTR_GEMM_MID_M"); return e ? atoi(e) : 3072; }();
+    static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 0; }();
+    static const int deep = [] { const char* e = getenv("LTR_GEMM_SMALL_DEEP"); return e ? atoi(e) : 0; }();
+    if (g.K % SKS == 0 && (g.M <= small_m || g.M <= mid_m)) {
+      const bool sm = g.M <= small_m;
+      const int bm = sm ? 32 : 64, bnn = sm ? 64 : 128;
+      if (g.N % 64 == 0 && (sm || g.N % 128 == 0)) {
+        const int tm_ = (g.M + bm - 1) / bm, tn_ = g.N / bnn;
+        // XCD grid: as many column ranges as keep an XCD's share of the weight matrix near 1.5 MB (and no more than
+        // there are column tiles), the rest of the 8 XCDs split the rows.  map_mode 0: every XCD a row range.
+        int cx = 1;
+        if (map_mode) while (cx < 8 && cx * 2 <= tn_ && (size_t)g.N * g.K * 2 / cx > (size_t)3 << 19) cx *= 2;
+        if (map_mode == 2) { cx = 8; while (cx > tn_) cx /= 2; }
+        XcdMap xm{NXCD / cx, cx, 0};
+        {
+          int lo, a, b;
+          xcd_range(tm_, xm.rx, 0, lo, a);
+          xcd_range(tn_, xm.cx, 0, lo, b);
+          xm.per_xcd = a * b;                                          // range 0 is never the shorter one
+        }
+        dim3 sgrid(xm.per_xcd * NXCD);
+#define LTR_SMALL_LAUNCH(LN, BMv, BNv, STv)                                                                                \
+  do {                                                                                                                     \
+    typedef SmallCfg<BMv, BNv, STv> Cfg;                                                                                   \
+    static const bool attr_ok = [] {                                                                                       \
+      return hipFuncSetAttribute((const void*)gemm_f16s_small_kernel<LN, BMv, BNv, STv>,                                   \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) == hipSuccess;           \
+    }();                                                                                                                   \
+    (void)attr_ok;                                                                                                         \
+    gemm_f16s_small_kernel<LN, BMv, BNv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(                                  \
+        (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, g.K, tm_, tn_, xm, ep);                \
+  } while (0)
+#define LTR_SMALL_LN(BMv, BNv, STv)                                                                                        \
+  do {                                                                                                                     \
+    if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, BMv, BNv, STv); else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, BMv, BNv, STv);       \
+    else LTR_SMALL_LAUNCH(LN_NONE, BMv, BNv, STv);                                                                         \
+  } while (0)
+        if (sm) {
+          // at most one workgroup per CU anyway: spend the LDS on a ring of eight (7 stages = 112 KB in flight per CU)
+          if (deep && tm_ * tn_ <= 256) LTR_SMALL_LN(32, 64, 8); else LTR_SMALL_LN(32, 64, 4);
+        } else {
+          LTR_SMALL_LN(64, 128, 4);
+        }
+#undef LTR_SMALL_LN
+#undef LTR_SMALL_LAUNCH
+        LTR_LAUNCH_CHECK();
+        return LTR_OK;
+      }
+    }
     if (lnm == LNP)
       gemm_f16s_kernel<LNP><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
                                                  g.N, g.K, tiles_m, tiles_n, gm, ep);
