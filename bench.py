@@ -236,6 +236,8 @@ def main():
                     help="steady calls to time outside the timed region: k new requests scored + the whole queue re-ranked "
                          "(SURVEY 8d 'steady'); comma list, '0' = none")
     ap.add_argument("--no-strong", action="store_true", help="skip the 65,536-request strong-scaling point")
+    ap.add_argument("--no-class-head", action="store_true",
+                    help="skip the class-mode head measurement (8,192 requests x 8,192 labels, kernels.class_head)")
     ap.add_argument("--sweep", action="store_true", help="extra JSON line: cold call at 256 ... 64k requests")
     ap.add_argument("--trace", default=None, choices=["burst", "gamma"], help="config 5 ranker-side trace replay")
     ap.add_argument("--trace-requests", type=int, default=2000)
@@ -369,6 +371,33 @@ def main():
                          tokens_rank0_shard=int(c64.cu[c64.r1] - c64.cu[c64.r0]))
         c64.release(); del c64
 
+    # ---- class-mode head at the reference's largest bucket count (train/train.sh: 8,192 labels; opt.py:389-397): the
+    # head of an 8,192-request call = final LayerNorm of the last-token rows + [8192, De] x [8192, De]^T logits on the
+    # split-fp16 MFMA kernel + row argmax.  One-token prompts keep the forward in front of it negligible.
+    class_head = None
+    if rank == 0 and world == 1 and not args.no_class_head and args.weight_dtype == "f16" and not args.sweep:
+        spec_c = OPTSpec.opt_125m(8192) if args.model == "125m" else OPTSpec.opt_350m(8192)
+        ck = dict(ckpt)
+        ck["score.weight"] = (0.05 * np.random.RandomState(1).standard_normal((8192, spec.word_embed_proj_dim))).astype(np.float16)
+        sc_c = HipOPTScorer(spec_c, ck, str(dev), "f16")
+        n_c = 8192
+        ids_c = torch.full((n_c,), 2, dtype=torch.int64, device=dev)
+        cu_c = np.arange(n_c + 1, dtype=np.int32)
+        cu_c_d = torch.from_numpy(cu_c).to(dev)
+        out_c = torch.empty(n_c, device=dev)
+        for _ in range(2):
+            sc_c.score_device(ids_c, cu_c_d, cu_c, out=out_c)
+        sc_c.profile(True); sc_c.profile_read(reset=True)
+        for _ in range(5):
+            sc_c.score_device(ids_c, cu_c_d, cu_c, out=out_c)
+        pc = sc_c.profile_read(reset=True)["pool"]
+        ms_c = pc["ms"] / 5
+        fl = 2.0 * n_c * 8192 * spec.word_embed_proj_dim
+        class_head = dict(requests=n_c, num_labels=8192, ms=ms_c, launches=pc["launches"] // 5,
+                          logits_tflops=fl / (ms_c * 1e-3) / 1e12,
+                          note="LayerNorm / project_out of the last-token rows + logits GEMM + argmax, per call")
+        sc_c.close(); del sc_c, ids_c, out_c
+
     if rank == 0:
         lin, att = model_flops(spec, lens[my_r0:my_r1])        # this rank's shard: what its profiler timed
         kernels, roof = {}, None
@@ -434,6 +463,8 @@ def main():
                     "pmc": pmc}
         # steady rank step (nothing new to score): 37 B per request per step algorithmic
         rk_us = rank_ms[len(rank_ms) // 2] * 1e3
+        if class_head:
+            kernels["class_head"] = class_head
         kernels["rank_step"] = dict(us_per_step=rk_us, launches_per_step=2 if n_total <= 12288 else 9,
                                     gbs=37.0 * n_total / (rk_us * 1e-6) / 1e9,
                                     frac_hbm=37.0 * n_total / (rk_us * 1e-6) / 1e9 / PEAK_HBM_GBS,

@@ -154,7 +154,10 @@ class OracleOPTScorer:
         ``logits[:, 0]`` (opt.py:408); class mode ``float(argmax)`` (:394-395)."""
         lg = self.logits(ids, cu_seqlens)
         if self.spec.num_labels > 1:
-            lg = lg[:, :self.spec.num_labels].argmax(dim=-1, keepdim=True).float()
+            # LogitsProcessor._get_logits cuts the logits at vocab_size columns ("remove paddings in vocab",
+            # layers/logits_processor.py:68-70; LogitsProcessor(config.vocab_size), opt.py:375) before opt.py:395 takes
+            # the argmax over [:num_labels]: with fewer vocabulary entries than labels only the first vocab_size compete
+            lg = lg[:, :min(self.spec.num_labels, self.spec.vocab_size)].argmax(dim=-1, keepdim=True).float()
         return lg[:, 0].float().numpy().astype(np.float32)
 
     def score_packed(self, ids: np.ndarray, cu_seqlens: np.ndarray,

@@ -29,7 +29,8 @@ def _scorer(spec, ckpt, dev, mode, **kw):
     return HipOPTScorer(spec, ckpt, device=dev, weight_dtype=mode, **kw)
 
 
-TINY = ["tiny_pre_ln", "tiny_post_ln", "tiny_pre_ln_class10", "tiny_post_ln_class7"]
+TINY = ["tiny_pre_ln", "tiny_post_ln", "tiny_pre_ln_class10", "tiny_post_ln_class7", "tiny_pre_ln_class82",
+        "tiny_post_ln_class820", "tiny_post_ln_v1024_class820"]
 
 
 @pytest.mark.parametrize("mode", ["f16", "f32"])
@@ -49,9 +50,39 @@ def test_golden_tiny(dev, name, mode):
         np.testing.assert_allclose(logits, z["hf_logits"], atol=TOL, rtol=0)
         # class mode: float(argmax) (opt.py:394-395); a flipped argmax is only legitimate
         # when the top two logits are closer than the tolerance
-        top2 = np.sort(z["hf_logits"], -1)[:, -2:]
+        # (over the labels that survive the reference's vocab_size cut, logits_processor.py:68-70)
+        top2 = np.sort(z["hf_logits"][:, :min(spec.num_labels, spec.vocab_size)], -1)[:, -2:]
         safe = (top2[:, 1] - top2[:, 0]) > 2 * TOL
+        assert safe.sum() >= len(got) // 2
         assert (got[safe] == z["ref_score"][safe]).all()
+        assert (got == np.floor(got)).all() and got.min() >= 0 and got.max() < min(spec.num_labels, spec.vocab_size)
+
+
+def test_class_mode_head_at_8192_labels_true_width(dev):
+    """The reference's largest class head (train/train.sh: bucket size 1 over 8192 -> 8,192 labels; tpt-class8192-xxx in
+    benchmarks/): OPT-125m width, logits against HF at 1e-4, the label against the reference where the top-2 gap exceeds
+    2e-4, and torch.argmax's FIRST-maximum rule on exact ties (two identical rows of score.weight)."""
+    z = np.load(os.path.join(GOLDEN, "score_opt125m_class8192.npz"))
+    spec = spec_from_npz(z)
+    assert spec.num_labels == 8192
+    ckpt = seeded_checkpoint(spec, int(z["seed"]))
+    sc = _scorer(spec, ckpt, dev, "f16")
+    got, logits = sc.score(z["ids"], z["cu_seqlens"], return_logits=True)
+    err = np.abs(logits - z["hf_logits"]).max()
+    top2 = np.sort(z["hf_logits"], -1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 2 * TOL
+    print(f"class head, 8192 labels: max|logit - HF| = {err:.3e}; {int(safe.sum())} of {len(got)} requests with a clear top-2 gap")
+    assert err <= TOL and safe.sum() >= len(got) - 2
+    assert (got[safe] == z["ref_score"][safe]).all()
+    assert (got == logits.argmax(-1)).all()                  # the label IS the argmax of the logits handed back
+    # exact ties: copy the winning row of score.weight of request 0 to a LATER and an EARLIER label
+    w = ckpt["score.weight"].copy()
+    win = int(got[0])
+    lo, hi = (win - 5) % 8192, (win + 7) % 8192
+    w[lo] = w[win]; w[hi] = w[win]
+    ck2 = dict(ckpt); ck2["score.weight"] = w
+    got2 = _scorer(spec, ck2, dev, "f16").score(z["ids"], z["cu_seqlens"])
+    assert got2[0] == min(win, lo, hi)
 
 
 @pytest.mark.parametrize("name,mode", [("opt125m", "f16"), ("opt125m", "f32"), ("opt350m", "f16")])

@@ -22,8 +22,9 @@ def _spec_from(npz) -> OPTSpec:
     return OPTSpec(**conv)
 
 
-SCORE_CASES = ["tiny_pre_ln", "tiny_post_ln", "tiny_pre_ln_class10", "tiny_post_ln_class7"]
-BIG_CASES = ["opt125m", "opt350m"]
+SCORE_CASES = ["tiny_pre_ln", "tiny_post_ln", "tiny_pre_ln_class10", "tiny_post_ln_class7", "tiny_pre_ln_class82",
+               "tiny_post_ln_class820", "tiny_post_ln_v1024_class820"]
+BIG_CASES = ["opt125m", "opt350m", "opt125m_class8192"]
 
 
 @pytest.mark.parametrize("name", SCORE_CASES + BIG_CASES)
@@ -43,11 +44,21 @@ def test_scorer_matches_reference(name):
         np.testing.assert_allclose(got, z["ref_score"], atol=atol, rtol=0)
         np.testing.assert_allclose(got, z["hf_logits"][:, 0], atol=atol, rtol=0)
     else:
-        assert (got == z["ref_score"]).all()
-        assert (got == z["hf_logits"].argmax(-1)).all()
+        # class mode: float(argmax) over the labels that survive the reference's vocab_size cut (logits_processor.py:68-70);
+        # where the two largest logits are closer than f32 noise the label may legitimately differ
+        cut = z["hf_logits"][:, :min(spec.num_labels, spec.vocab_size)]
+        top2 = np.sort(cut, -1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-5
+        assert clear.sum() >= len(got) - 2
+        assert (got[clear] == z["ref_score"][clear]).all()
+        assert (got[clear] == cut.argmax(-1)[clear]).all()
+        np.testing.assert_allclose(orc.logits(z["ids"], z["cu_seqlens"]).numpy(), z["hf_logits"], atol=atol, rtol=0)
     # batch-composition independence (SURVEY 7 'varlen batching'): packed == flat
     packed = orc.score_packed(z["ids"], z["cu_seqlens"], max_tokens=256 if name not in BIG_CASES else 2048)
-    np.testing.assert_allclose(packed, got, atol=atol, rtol=0)
+    if spec.num_labels == 1:
+        np.testing.assert_allclose(packed, got, atol=atol, rtol=0)
+    else:
+        assert (packed[clear] == got[clear]).all()
 
 
 def test_scorer_empty():

@@ -61,6 +61,12 @@ struct ltr_model {
   bool lastq = false;
   const void* last_q_w = nullptr;
   const void* last_kv_w = nullptr;
+  // F16 mode, head on the matrix cores (run_forward "GEMM head"): slab-major images of project_out [De, H] (350m style)
+  // and of score.weight padded with zero rows to a multiple of 64 labels [head_lpad, De] (class mode with many labels:
+  // train/train.sh:19-44 trains 82 / 820 / 8192-label heads)
+  const void* proj_out_w = nullptr;
+  const void* head_w = nullptr;
+  int head_lpad = 0;
   ~ltr_model() {
     if (packed) (void)hipFree(packed);
     if (fold) (void)hipFree(fold);
@@ -107,10 +113,16 @@ struct Workspace {
   AOp a2;
   void* stats1;
   void* stats2;
+  // GEMM head: compact last-token rows f32 [Nc, H] (only when the forward did not compact them), their operand
+  // [Nc, H], the project_out result (operand or f32) [Nc, De], the padded logits f32 [Nc, lpad]
+  float* head_rows;
+  AOp head_op;
+  char* head_feat;
+  float* head_logits;
   size_t bytes;
 };
 
-Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, bool ln_fold = false) {
+Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, bool ln_fold = false, int head_lpad = -1) {
   const size_t H = d.hidden_size, F = d.ffn_dim;
   const size_t esz = 4;   // operand bytes per element: f32, or fp16 hi + fp16 lo
   char* p = (char*)base;
@@ -127,6 +139,14 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, boo
     ws.a2 = AOp{a2, a2 ? a2 + Tc * H * 2 : nullptr};
     ws.stats1 = take((H / 64) * Tc * 8);
     ws.stats2 = take((H / 64) * Tc * 8);
+  }
+  if (head_lpad >= 0) {        // the GEMM head is in use (head_lpad = 0: project_out only)
+    const size_t De = d.word_embed_proj_dim;
+    ws.head_rows = (float*)take(Nc * H * 4);
+    char* ho = (char*)take(Nc * H * esz);
+    ws.head_op = AOp{ho, ho ? ho + Nc * H * 2 : nullptr};
+    ws.head_feat = (char*)take(Nc * De * esz);
+    ws.head_logits = (float*)take((size_t)Nc * (head_lpad > 0 ? head_lpad : 1) * 4);
   }
   if (d.weight_dtype == LTR_W_F16) {
     ws.a = AOp{a, a ? a + Tc * H * 2 : nullptr};
@@ -352,6 +372,10 @@ int check_desc(const ltr_model_desc& d) {
   return LTR_OK;
 }
 
+// GEMM head (F16 mode): -1 = not used (the VALU pool_head_kernel does everything), 0 = project_out on the matrix cores
+// only, > 0 = also the class logits, padded to that many labels
+int head_mode(const ltr_model* m) { return m->proj_out_w || m->head_w ? m->head_lpad : -1; }
+
 // tokens per chunk: never below the longest legal request (pos_rows - 2 positions)
 int64_t chunk_cap(const ltr_model* m) {
   const int64_t maxpos = m->d.pos_rows - 2;
@@ -433,7 +457,14 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
     }
     { const char* e = getenv("LTR_NO_LASTQ"); m->lastq = desc->num_layers > 0 && !m->dbg_attn_valu && !(e && e[0] == '1'); }
     const size_t last_bytes = m->lastq ? 3 * H * H * 2 : 0;   // H * H and 2H * H halves: both multiples of 256 B
-    size_t total = last_bytes;
+    // head on the matrix cores: project_out when there is one, the class logits from LTR_HEAD_GEMM_MIN_LABELS (17) labels
+    int min_labels = 17;
+    { const char* e = getenv("LTR_HEAD_GEMM_MIN_LABELS"); if (e) min_labels = atoi(e); }
+    const bool pack_proj = proj && De % 64 == 0;
+    const bool pack_head = desc->num_labels >= min_labels && min_labels > 0 && De % 64 == 0;
+    const size_t lpad = pack_head ? ((size_t)desc->num_labels + 63) / 64 * 64 : 0;
+    const size_t head_bytes = (pack_proj ? De * H * 2 : 0) + lpad * De * 2;        // both multiples of 256 B
+    size_t total = last_bytes + head_bytes;
     for (auto& it : items) total += (it.n * it.k * 2 + 255) / 256 * 256;
     if (total) {
       if (hipMalloc(&m->packed, total) != hipSuccess) {
@@ -455,6 +486,20 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
         if ((rc = launch_pack_weight(src, dq, (int)H, (int)H, cs)) ||
             (rc = launch_pack_weight(src + H * H * 2, dkv, (int)(2 * H), (int)H, cs))) { delete m; return rc; }
         m->last_q_w = dq; m->last_kv_w = dkv;
+        off += last_bytes;
+      }
+      if (pack_proj) {
+        void* dst = (char*)m->packed + off;
+        if ((rc = launch_pack_weight(m->w[LTR_WT_PROJECT_OUT], dst, (int)De, (int)H, cs))) { delete m; return rc; }
+        m->proj_out_w = dst;
+        off += De * H * 2;
+      }
+      if (pack_head) {
+        void* dst = (char*)m->packed + off;
+        if ((rc = launch_pack_weight(m->w[LTR_WT_SCORE], dst, (int)lpad, (int)De, cs, desc->num_labels))) { delete m; return rc; }
+        m->head_w = dst;
+        m->head_lpad = (int)lpad;
+        off += lpad * De * 2;
       }
     }
   }
@@ -525,7 +570,7 @@ size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
   if (kind == LTR_WS_SCORE && h) {
     int64_t Tc = T < chunk_cap(h) ? T : chunk_cap(h);
     int64_t Nc = N < Tc ? N : Tc;
-    return carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold).bytes;
+    return carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold, head_mode(h)).bytes;
   }
   return 0;
 }
@@ -554,7 +599,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
   }
   // chunk budget from the workspace actually provided
   int64_t Tc_cap = chunk_cap(h) < T ? chunk_cap(h) : T;
-  while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr, h->ln_fold).bytes > ws_bytes) Tc_cap /= 2;
+  while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr, h->ln_fold, head_mode(h)).bytes > ws_bytes) Tc_cap /= 2;
   int r0 = 0;
   while (r0 < N) {
     int r1 = r0;
@@ -571,7 +616,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
       return LTR_E_NOMEM;
     }
     const int t0 = cu[r0], t1 = cu[r1];
-    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace, h->ln_fold);
+    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace, h->ln_fold, head_mode(h));
     if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
     if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
     double sum_l2 = 0.0;
@@ -583,13 +628,55 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     if (hidden_out) {
       LTR_HIP_CHECK(hipMemcpyAsync(hidden_out, ws.h, (size_t)(t1 - t0) * d.hidden_size * 4, hipMemcpyDeviceToDevice, s));
     } else {
-      ProfScope p(h, LTR_K_POOL, (double)(r1 - r0) * (d.hidden_size * 4.0 + 4.0), s);
-      rc = launch_pool_head(d.weight_dtype, h_final, prune ? nullptr : cu_seqlens + r0, t0, r1 - r0, d.hidden_size,
-                            d.word_embed_proj_dim,
-                            d.num_labels, (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
-                            d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
-                            h->gw(LTR_WT_SCORE), scores_out + r0, logits_out ? logits_out + (size_t)r0 * d.num_labels : nullptr, s);
-      if (rc) return rc;
+      const int n = r1 - r0, H = d.hidden_size, De = d.word_embed_proj_dim, wd = d.weight_dtype;
+      const int n_cmp = d.num_labels < d.vocab_size ? d.num_labels : d.vocab_size;   // logits_processor.py:68-70
+      const bool proj = De != H;
+      float* scores_dst = scores_out + r0;
+      float* logits_dst = logits_out ? logits_out + (size_t)r0 * d.num_labels : nullptr;
+      if (head_mode(h) < 0) {
+        ProfScope p(h, LTR_K_POOL, (double)n * (H * 4.0 + 4.0), s);
+        rc = launch_pool_head(wd, h_final, prune ? nullptr : cu_seqlens + r0, t0, n, H, De, d.num_labels, n_cmp,
+                              (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
+                              proj ? h->gw(LTR_WT_PROJECT_OUT) : nullptr, h->gw(LTR_WT_SCORE), scores_dst, logits_dst, s);
+        if (rc) return rc;
+      } else {
+        // ---- GEMM head (F16 mode).  Final LayerNorm / project_out / score.weight are per-row maps of the n last-token
+        // rows (logits_processor.py:74-79, opt.py:259-262,374): the LayerNorm writes the rows as a split operand,
+        // project_out [n, H] x [De, H]^T and - in class mode - the logits [n, De] x [labels, De]^T run on the
+        // split-fp16 MFMA kernels (8,192 labels x 8,192 requests is a 103 GFLOP GEMM, not 2,048 serial wave reductions
+        // per request), then one argmax pass (first maximum, opt.py:394-395).  Rank mode keeps the VALU dot product.
+        ProfScope p(h, LTR_K_POOL, (double)n * (H * 4.0 + 4.0), s);
+        const float* rows = h_final;
+        if (!prune) {          // the forward left all T rows: compact the last-token rows first
+          if ((rc = launch_gather_last_rows(wd, cu_seqlens + r0, t0, n, H, h_final, AOp{nullptr, nullptr}, ws.head_rows,
+                                            AOp{nullptr, nullptr}, s))) return rc;
+          rows = ws.head_rows;
+        }
+        const float* ln_w = (const float*)h->gw(LTR_WT_FINAL_LN_W);
+        if (ln_w) rc = launch_layernorm(wd, rows, ln_w, (const float*)h->gw(LTR_WT_FINAL_LN_B), n, H, nullptr, ws.head_op, s);
+        else rc = launch_to_operand(wd, rows, n, H, ws.head_op, s);
+        if (rc) return rc;
+        AOp feat = ws.head_op;                       // [n, De] operand of the label GEMM
+        const bool labels_gemm = h->head_w != nullptr;
+        if (proj) {
+          GemmArgs g{};
+          g.a = ws.head_op; g.w = h->proj_out_w; g.M = n; g.N = De; g.K = H; g.a_slab = 1;
+          if (labels_gemm) { feat = AOp{ws.head_feat, ws.head_feat + (size_t)n * De * 2}; g.out_split = feat; g.out_slab = 1; }
+          else g.out_f32 = (float*)ws.head_feat;
+          if ((rc = launch_gemm(wd, g, s))) return rc;
+        }
+        if (labels_gemm) {
+          GemmArgs g{};
+          g.a = feat; g.w = h->head_w; g.out_f32 = ws.head_logits; g.M = n; g.N = h->head_lpad; g.K = De; g.a_slab = 1;
+          if ((rc = launch_gemm(wd, g, s))) return rc;
+          if ((rc = launch_argmax_rows(ws.head_logits, h->head_lpad, n, n_cmp, d.num_labels, scores_dst, logits_dst, s))) return rc;
+        } else {
+          // few labels: dot products of the De-wide feature rows on the VALU (no LayerNorm, no projection left to do)
+          rc = launch_pool_head(wd, (const float*)ws.head_feat, nullptr, 0, n, De, De, d.num_labels, n_cmp, nullptr, nullptr,
+                                nullptr, h->gw(LTR_WT_SCORE), scores_dst, logits_dst, s);
+          if (rc) return rc;
+        }
+      }
     }
     r0 = r1;
   }
@@ -632,6 +719,7 @@ int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, 
   const ltr_model_desc& d = h->d;
   DeviceGuard guard(h->device);
   return launch_pool_head(d.weight_dtype, hidden, cu_seqlens, 0, N, d.hidden_size, d.word_embed_proj_dim, d.num_labels,
+                          d.num_labels < d.vocab_size ? d.num_labels : d.vocab_size,
                           (const float*)h->gw(LTR_WT_FINAL_LN_W), (const float*)h->gw(LTR_WT_FINAL_LN_B),
                           d.word_embed_proj_dim != d.hidden_size ? h->gw(LTR_WT_PROJECT_OUT) : nullptr,
                           h->gw(LTR_WT_SCORE), scores_out, logits_out, (hipStream_t)stream);

@@ -786,14 +786,15 @@ int gemm_timeline_read(unsigned long long* host) { return (int)hipMemcpyFromSymb
 namespace {
 // nn.Linear weight [N][K] (K contiguous) -> slab-major image [K/32][N][32]; one 16-B piece per thread
 __global__ void __launch_bounds__(256) pack_weight_kernel(const __half* __restrict__ src, __half* __restrict__ dst, int N,
-                                                          int K) {
+                                                          int K, int n_src) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // piece index in the destination
   const size_t pieces = (size_t)N * K / 8;
   if (i >= pieces) return;
   const int c = (int)(i & 3);                 // 16-B chunk inside the 64-B slab row
   const size_t rn = i >> 2;                   // slab * N + n
   const int n = (int)(rn % N), slab = (int)(rn / N);
-  *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(src + (size_t)n * K + slab * BK16 + c * 8);
+  *reinterpret_cast<uint4*>(dst + i * 8) =
+      n < n_src ? *reinterpret_cast<const uint4*>(src + (size_t)n * K + slab * BK16 + c * 8) : make_uint4(0, 0, 0, 0);
 }
 
 }  // namespace
@@ -826,10 +827,11 @@ int launch_ln_fold_coeff(const void* w_f16, const float* gamma, const float* bet
   return LTR_OK;
 }
 
-int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s) {
+int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s, int n_src) {
   if (K % BK16) { set_error("pack_weight: K=%d must be a multiple of %d", K, BK16); return LTR_E_INVAL; }
   const size_t pieces = (size_t)N * K / 8;
-  pack_weight_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>((const __half*)src, (__half*)dst, N, K);
+  pack_weight_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>((const __half*)src, (__half*)dst, N, K,
+                                                                      n_src < 0 ? N : n_src);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }

@@ -74,7 +74,9 @@ struct GemmArgs {
 
 // launchers (each in its own .hip file)
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
-int launch_pack_weight(const void* src_f16 /*[N,K]*/, void* dst_f16 /*[K/32][N][32]*/, int N, int K, hipStream_t s);
+// n_src < N: the source has n_src rows, the image is padded with zero rows up to N (N a multiple of 64 for launch_gemm)
+int launch_pack_weight(const void* src_f16 /*[N,K]*/, void* dst_f16 /*[K/32][N][32]*/, int N, int K, hipStream_t s,
+                       int n_src = -1);
 // c[n] = 16 * sum_k gamma_k W[n,k], d[n] = sum_k beta_k W[n,k] + bias[n]  (W row-major fp16, the checkpoint layout)
 int launch_ln_fold_coeff(const void* w_f16, const float* gamma, const float* beta, const float* bias, int N, int K,
                          float* c_out, float* d_out, hipStream_t s);
@@ -106,8 +108,13 @@ int launch_attention_lastq(const float* q, AOp kv, const int32_t* cu /*chunk-loc
 
 int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu /*nullptr: rows are already compact*/, int tok_off,
                      int N, int H, int De,
-                     int num_labels, const float* ln_w, const float* ln_b, const void* proj_out,
+                     int num_labels, int n_cmp /*labels that compete in the argmax: min(num_labels, vocab)*/,
+                     const float* ln_w, const float* ln_b, const void* proj_out,
                      const void* score_w, float* scores_out, float* logits_out, hipStream_t s);
+// class-mode label per row of logits f32 [n_rows, ld] (first maximum over the first n_cmp columns); logits_out f32
+// [n_rows, num_labels] or nullptr
+int launch_argmax_rows(const float* logits, int ld, int n_rows, int n_cmp, int num_labels, float* scores_out,
+                       float* logits_out, hipStream_t s);
 
 size_t rank_workspace_bytes(int64_t N);
 int launch_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,

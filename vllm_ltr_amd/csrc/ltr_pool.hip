@@ -34,7 +34,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 template <typename WT>
 __global__ void __launch_bounds__(PH_THREADS) pool_head_kernel(
-    const float* __restrict__ hidden, const int32_t* __restrict__ cu, int tok_off, int H, int De, int num_labels,
+    const float* __restrict__ hidden, const int32_t* __restrict__ cu, int tok_off, int H, int De, int num_labels, int n_cmp,
     const float* __restrict__ ln_w, const float* __restrict__ ln_b, const WT* __restrict__ proj_out,
     const WT* __restrict__ score_w, float* __restrict__ scores, float* __restrict__ logits_out) {
   __shared__ float s_x[PH_MAXH];
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(PH_THREADS) pool_head_kernel(
     }
     __syncthreads();
     if (tid == 0) {
-      for (int w = 0; w < 4 && j0 + w < num_labels; ++w)
+      for (int w = 0; w < 4 && j0 + w < n_cmp; ++w)            // labels past n_cmp do not compete (launch_pool_head)
         if (s_red[w] > s_best) { s_best = s_red[w]; s_besti = j0 + w; }
       if (j0 == 0 && num_labels == 1) scores[req] = s_red[0];
     }
@@ -95,19 +95,65 @@ __global__ void __launch_bounds__(PH_THREADS) pool_head_kernel(
   if (tid == 0 && num_labels > 1) scores[req] = (float)s_besti;
 }
 
+// Class-mode label of every row of a logits matrix (the GEMM head, ltr_api.hip): float(argmax_j logits[r, j]) over
+// j < n_cmp with torch.argmax's first-maximum rule (opt.py:394-395); optionally the unpadded logits are copied out.
+// One 256-thread workgroup per row; a thread walks its columns in increasing order and keeps the first maximum it
+// meets, threads / waves are merged by (larger value, then smaller index).
+__global__ void __launch_bounds__(256) argmax_rows_kernel(const float* __restrict__ logits, int ld, int n_cmp, int num_labels,
+                                                          float* __restrict__ scores, float* __restrict__ logits_out) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (size_t)r * ld;
+  constexpr int NONE = 0x7fffffff;
+  float best = -INFINITY;
+  int bi = NONE;
+  for (int j = tid; j < num_labels; j += 256) {
+    const float v = row[j];
+    if (logits_out) logits_out[(size_t)r * num_labels + j] = v;
+    if (j < n_cmp && (bi == NONE || v > best)) { best = v; bi = j; }   // strict >: the first maximum of this thread's columns
+  }
+  // merge two candidates: the larger value wins, equal values the smaller column (torch.argmax's first maximum)
+  auto take = [&](float ov, int oi) {
+    if (oi != NONE && (bi == NONE || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+  };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    take(ov, oi);
+  }
+  if (lane == 0) { s_v[wave] = best; s_i[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) take(s_v[w], s_i[w]);
+    scores[r] = (float)(bi == NONE ? 0 : bi);
+  }
+}
+
 }  // namespace
 
+int launch_argmax_rows(const float* logits, int ld, int n_rows, int n_cmp, int num_labels, float* scores_out,
+                       float* logits_out, hipStream_t s) {
+  if (n_rows == 0) return LTR_OK;
+  argmax_rows_kernel<<<n_rows, 256, 0, s>>>(logits, ld, n_cmp, num_labels, scores_out, logits_out);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+// n_cmp: number of leading labels that compete in the class-mode argmax - min(num_labels, vocab_size): the reference's
+// LogitsProcessor cuts the logits at vocab_size columns (layers/logits_processor.py:68-70) before opt.py:395
 int launch_pool_head(int wdtype, const float* hidden, const int32_t* cu, int tok_off, int N, int H, int De,
-                     int num_labels, const float* ln_w, const float* ln_b, const void* proj_out,
+                     int num_labels, int n_cmp, const float* ln_w, const float* ln_b, const void* proj_out,
                      const void* score_w, float* scores_out, float* logits_out, hipStream_t s) {
   if (N == 0) return LTR_OK;
   if (H > PH_MAXH || De > PH_MAXH) { set_error("pool_head: H/De > %d", PH_MAXH); return LTR_E_INVAL; }
   if (wdtype == LTR_W_F16)
-    pool_head_kernel<__half><<<N, PH_THREADS, 0, s>>>(hidden, cu, tok_off, H, De, num_labels, ln_w, ln_b,
+    pool_head_kernel<__half><<<N, PH_THREADS, 0, s>>>(hidden, cu, tok_off, H, De, num_labels, n_cmp, ln_w, ln_b,
                                                       (const __half*)proj_out, (const __half*)score_w, scores_out,
                                                       logits_out);
   else
-    pool_head_kernel<float><<<N, PH_THREADS, 0, s>>>(hidden, cu, tok_off, H, De, num_labels, ln_w, ln_b,
+    pool_head_kernel<float><<<N, PH_THREADS, 0, s>>>(hidden, cu, tok_off, H, De, num_labels, n_cmp, ln_w, ln_b,
                                                      (const float*)proj_out, (const float*)score_w, scores_out,
                                                      logits_out);
   LTR_LAUNCH_CHECK();
