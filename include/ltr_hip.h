@@ -176,6 +176,16 @@ int ltr_embed_gather(ltr_handle h, const int64_t* token_ids, const int32_t* cu_s
 int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, int32_t N,
                   float* scores_out, float* logits_out, void* stream);
 
+/* The varlen causal self-attention of a decoder layer alone (OPTAttention.forward, opt.py:92-102,
+ * with kv_cache None: attention/backends/rocm_flash_attn.py:244-290 on the GPU, torch_sdpa.py:138-178 in the CPU oracle):
+ * out[t] = softmax_{s <= t, same request}(q[t] . k[s] / 8) v[s] per head of 64, requests delimited by cu_seqlens.
+ *   qkv  LTR_W_F16: fp16 hi | lo planes [2][T, 3H] (q | k | v per row; value = hi + lo), LTR_W_F32: f32 [T, 3H]
+ *   out  LTR_W_F16: fp16 hi | lo planes [2][T, H] row-major,                             LTR_W_F32: f32 [T, H]
+ *   workspace: (N + 4) * 4 + (T / 64 + N + 1) * 16 bytes (the work list of query blocks).
+ * Test / roofline hook: ltr_score runs the same kernel inside every layer. */
+int ltr_attention(ltr_handle h, const void* qkv, const int32_t* cu_seqlens, int32_t N, int32_t T, void* out,
+                  void* workspace, size_t ws_bytes, void* stream);
+
 /* One ranking step over the queued requests: the body of
  * Scheduler._get_opt_ordered_requests after scoring (vllm/core/scheduler.py:984-998).
  *

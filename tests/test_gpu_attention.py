@@ -1,0 +1,68 @@
+"""-m gpu: the varlen causal attention kernels ALONE against the oracle's per-sequence
+softmax(q k^T / 8) v (oracle/opt_scorer.py::attention = torch_sdpa.py:138-178 semantics), through the C ABI
+(``ltr_attention``).  The scorer tests see attention only through whole layers; this pins the kernel itself at the lengths
+where its tiling changes: 1, 31 / 32 / 33 (one key tile), 128 / 129 (one / two query blocks), 1024, 2048 (the position
+table's limit), mixed in one ragged batch with non-trivial offsets."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.opt_scorer import OracleOPTScorer
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+
+pytestmark = pytest.mark.gpu
+
+LENS = [1, 31, 32, 33, 128, 129, 1024, 2048, 5, 64, 65, 1, 300, 127]
+
+
+def _qkv(T, H, seed, scale_q):
+    r = np.random.RandomState(seed)
+    x = r.standard_normal((T, 3 * H)).astype(np.float32)
+    x[:, :H] *= scale_q                      # sharper or flatter softmax
+    x[:, H:2 * H] *= 1.5
+    return x
+
+
+@pytest.mark.parametrize("model,mode", [("125m", "f16"), ("350m", "f16"), ("125m", "f32")])
+@pytest.mark.parametrize("scale_q", [0.5, 4.0])
+def test_attention_kernel_alone_vs_oracle(model, mode, scale_q):
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = (OPTSpec.opt_125m() if model == "125m" else OPTSpec.opt_350m())
+    spec1 = OPTSpec(**{**spec.__dict__, "num_hidden_layers": 1})          # the handle only supplies H / heads / mode
+    ckpt = seeded_checkpoint(spec1, 0)
+    if mode == "f32":
+        ckpt = {k: v.astype(np.float32) for k, v in ckpt.items()}
+    sc = HipOPTScorer(spec1, ckpt, "cuda:0", mode)
+    H = spec.hidden_size
+    lens = LENS if mode == "f16" else [1, 31, 32, 33, 128, 129, 300]       # the f32 VALU kernel is the slow cross-check path
+    T = int(np.sum(lens))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = _qkv(T, H, 3, scale_q)
+    want = OracleOPTScorer(spec1, ckpt, dtype=torch.float64).attention(torch.from_numpy(x).double(), lens).numpy()
+    dev = torch.device("cuda:0")
+    cu_d = torch.from_numpy(cu).to(dev)
+    xt = torch.from_numpy(x).to(dev)
+    if mode == "f16":
+        hi = xt.to(torch.float16)
+        lo = (xt - hi.float()).to(torch.float16)
+        qkv = torch.stack([hi, lo]).contiguous()
+        out = torch.full((2, T, H), float("nan"), dtype=torch.float16, device=dev)
+        sc.attention_device(qkv, cu_d, len(lens), T, out)
+        got = (out[0].double() + out[1].double()).cpu().numpy()
+        # the kernel sees hi + lo (22 bits of x): compare with the oracle on exactly those inputs
+        x_seen = (hi.double() + lo.double()).cpu().numpy()
+        want = OracleOPTScorer(spec1, ckpt, dtype=torch.float64).attention(torch.from_numpy(x_seen), lens).numpy()
+    else:
+        out = torch.full((T, H), float("nan"), dtype=torch.float32, device=dev)
+        sc.attention_device(xt, cu_d, len(lens), T, out)
+        got = out.double().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - want)
+    scale = np.abs(want).max()
+    worst = int(err.max(axis=1).argmax())
+    req = int(np.searchsorted(cu, worst, side="right") - 1)
+    print(f"{model}/{mode} q-scale {scale_q}: T = {T}, max|out - oracle| = {err.max():.3e} (|out| <= {scale:.2f}) at row {worst} "
+          f"= position {worst - cu[req]} of a {lens[req]}-token request")
+    # outputs are convex combinations of v ~ N(0, 1): absolute tolerance.  f16 path: products of split operands
+    # (dropped lo.lo terms 2^-22) + an fp16 hi|lo output; f32 path: plain f32 arithmetic
+    assert err.max() <= 3e-6 * max(1.0, scale)

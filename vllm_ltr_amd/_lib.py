@@ -24,7 +24,7 @@ SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "lt
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
-           "ltr_train_step", "ltr_train_read")
+           "ltr_train_step", "ltr_train_read", "ltr_attention")
 ABI_VERSION = 2
 
 
@@ -100,6 +100,7 @@ def _load() -> C.CDLL:
     lib.ltr_forward_hidden.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.ltr_embed_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ltr_pool_head.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    lib.ltr_attention.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.ltr_rank_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, sz, vp]
     lib.ltr_age_update.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
     lib.ltr_queue_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, u32, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]

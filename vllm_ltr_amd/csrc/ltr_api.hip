@@ -725,6 +725,23 @@ int ltr_pool_head(ltr_handle h, const float* hidden, const int32_t* cu_seqlens, 
                           h->gw(LTR_WT_SCORE), scores_out, logits_out, (hipStream_t)stream);
 }
 
+int ltr_attention(ltr_handle h, const void* qkv, const int32_t* cu_seqlens, int32_t N, int32_t T, void* out, void* workspace,
+                  size_t ws_bytes, void* stream) {
+  if (!h || N < 0 || T < 0) { set_error("ltr_attention: bad argument"); return LTR_E_INVAL; }
+  if (N == 0 || T == 0) return LTR_OK;
+  if (!qkv || !cu_seqlens || !out || !workspace) { set_error("ltr_attention: NULL pointer"); return LTR_E_INVAL; }
+  const size_t need = (size_t)(N + 4) * 4 + ((size_t)T / 64 + N + 1) * 16;
+  if (ws_bytes < need) { set_error("ltr_attention: workspace too small (%zu < %zu)", ws_bytes, need); return LTR_E_NOMEM; }
+  const ltr_model_desc& d = h->d;
+  const size_t H = d.hidden_size;
+  DeviceGuard guard(h->device);
+  const bool f16 = d.weight_dtype == LTR_W_F16;
+  AOp in{(void*)qkv, f16 ? (void*)((char*)qkv + (size_t)T * 3 * H * 2) : nullptr};
+  AOp o{out, f16 ? (void*)((char*)out + (size_t)T * H * 2) : nullptr};
+  return launch_attention(d.weight_dtype, in, cu_seqlens, N, T, (int)H, d.num_heads, (int32_t*)workspace, o, 1,
+                          (hipStream_t)stream);
+}
+
 int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,
                   const int32_t* members, int32_t N, int32_t starv, int32_t period, uint32_t flags, int32_t* perm_out,
                   void* workspace, size_t ws_bytes, void* stream) {

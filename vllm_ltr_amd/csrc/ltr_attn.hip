@@ -209,7 +209,15 @@ constexpr int NSTAGE = 3;
 __device__ __forceinline__ int k_off(int row, int c) { return row * D + ((c ^ ((row >> 1) & 7)) << 3); }
 // V: 32-B column block cb of key row r sits at block cb ^ ((r >> 1) & 1), so that the four key rows a
 // transpose read touches (two 256-B bank rows) fall on distinct banks
-__device__ __forceinline__ int v_off(int row, int d) { return row * D + ((((d >> 4) ^ ((row >> 1) & 1)) << 4) | (d & 15)); }
+// LTR_ATTN_VSWZ: which 16-B chunk index bits are flipped on odd row pairs (2 = 32-B blocks, round 1-2; 4 = 64-B halves;
+// 6 = both).  A transpose read covers 4 key rows x 64 B per 32 lanes: rows k, k+1 share a 256-B bank row, rows k+2, k+3
+// the next one, so without the 64-B flip rows k and k+2 sit on the same banks.
+#ifndef LTR_ATTN_VSWZ
+#define LTR_ATTN_VSWZ 6
+#endif
+__device__ __forceinline__ int v_off(int row, int d) {
+  return row * D + ((((d >> 3) ^ (((row >> 1) & 1) * LTR_ATTN_VSWZ)) << 3) | (d & 7));
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -257,7 +265,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   // tile loads: wave w fills rows 8w..8w+7 of each of the four planes (1 KiB each)
   const int lrow = wave * 8 + (lane >> 3);                      // key row inside the tile
   const int kc_log = (lane & 7) ^ ((lrow >> 1) & 7);            // K: swizzled source chunk
-  const int vc = (lane & 7) ^ (((lrow >> 1) & 1) << 1);         // V: 32-B blocks swapped on odd row pairs (v_off)
+  const int vc = (lane & 7) ^ (((lrow >> 1) & 1) * LTR_ATTN_VSWZ);   // V: chunk bits flipped on odd row pairs (v_off)
   auto issue = [&](int stage, int kt) {
     const size_t rowoff = (size_t)(t0 + min(kt + lrow, L - 1)) * ld + head * D;
     __half* base = smem + stage * ATT_STAGE + wave * 8 * D;

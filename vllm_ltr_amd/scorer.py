@@ -205,6 +205,14 @@ class HipOPTScorer:
                                              tok_out.data_ptr() if tok_out is not None else None,
                                              self._stream()), "ltr_embed_gather")
 
+    def attention_device(self, qkv: torch.Tensor, cu_dev: torch.Tensor, N: int, T: int, out: torch.Tensor) -> None:
+        """The varlen causal attention kernel alone (``ltr_attention``).  f16 mode: ``qkv`` fp16 [2, T, 3H] (hi | lo planes),
+        ``out`` fp16 [2, T, H]; f32 mode: f32 [T, 3H] -> f32 [T, H]."""
+        need = (N + 4) * 4 + (T // 64 + N + 1) * 16
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.ltr_attention(self._h, qkv.data_ptr(), cu_dev.data_ptr(), N, T, out.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), self._stream()), "ltr_attention")
+
     def pool_head_device(self, hidden: torch.Tensor, cu_dev: torch.Tensor, N: int, scores_out: torch.Tensor,
                          logits_out: Optional[torch.Tensor] = None) -> None:
         _lib.check(self.lib.ltr_pool_head(self._h, hidden.data_ptr(), cu_dev.data_ptr(), N, scores_out.data_ptr(),
