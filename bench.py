@@ -303,7 +303,7 @@ def main():
     # FLOP rate is not comparable with a plain GEMM's.  For the record, time the same call once more on a second handle
     # with the fold off (LTR_NO_LN_FOLD is read at ltr_create): `roofline.unfused` below.  Outside the timed region.
     unfused = None
-    if rank == 0 and args.weight_dtype == "f16" and spec.do_layer_norm_before and not args.no_unfused \
+    if rank == 0 and args.weight_dtype == "f16" and not args.no_unfused \
             and os.environ.get("LTR_NO_LN_FOLD") != "1":
         os.environ["LTR_NO_LN_FOLD"] = "1"
         try:

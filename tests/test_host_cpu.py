@@ -225,3 +225,26 @@ def test_schedule_type_xpt_table_path():
     st = parse_schedule_type("xpt{/data/dist/table.pt}-whatever")           # scheduler.py:312 slicing
     assert st.policy == "xpt" and st.need_score and st.table_path == "/data/dist/table.pt"
     assert parse_schedule_type("opt-starv3-period2").table_path == ""
+
+
+def test_gemm_kernels_do_not_spill():
+    """The split-fp16 GEMM kernels must fit their register budget without scratch: a spilled LayerNorm-fold instance
+    produced NaNs on the GPU (its inline-asm epilogue stores sat behind scratch reloads) - keep the
+    compiler's own report at zero for every gemm_f16s instance."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "vllm_ltr_amd", "csrc", "ltr_gemm.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+                        "-Wno-unused-function", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, seen = None, 0
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and "gemm_f16s" in name:
+            seen += 1
+            assert int(m.group(1)) == 0, f"{name} spills {m.group(1)} bytes per lane"
+    assert seen >= 10

@@ -265,6 +265,8 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       if ((rc = launch_gather_last_rows(wd, cu_dev + r0, t0, nreq, H, ws.h, AOp{nullptr, nullptr}, hb, AOp{nullptr, nullptr}, s)))
         return rc;
       if (d.pre_ln) rc = lnorm(nreq, hb, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ab);
+      else if (ln1_folded)   // post-LN fold: the gathered rows are x of the previous fc2, their LayerNorm is still pending
+        rc = lnorm(nreq, hb, (const float*)m->lw(L - 1, LTR_WL_LN2_W), (const float*)m->lw(L - 1, LTR_WL_LN2_B), hb, ab);
       else rc = launch_to_operand(wd, hb, nreq, H, ab, s);
       if (rc) return rc;
       float* qf = ws.h;
@@ -308,16 +310,34 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       fb = wd == LTR_W_F16 ? AOp{ws.f.hi, (char*)ws.f.hi + (size_t)nreq * F * 2} : ws.f;
       Mr = nreq;
       if ((rc = launch_gather_last_rows(wd, cu_dev + r0, t0, nreq, H, ws.h, ws.a, hb, ab, s))) return rc;
+      if (!d.pre_ln && ln1_folded) {   // post-LN fold: apply the pending LayerNorm of the previous fc2 to the compact rows
+        rc = lnorm(nreq, hb, (const float*)m->lw(L - 1, LTR_WL_LN2_W), (const float*)m->lw(L - 1, LTR_WL_LN2_B), hb,
+                   AOp{nullptr, nullptr});
+        if (rc) return rc;
+      }
     }
-    const bool fold_here = fold;                  // also on the n_req compact rows of the pruned last layer (M = n_req)
+    // pre-LN: also on the n_req compact rows of the pruned last layer (M = n_req).  Post-LN: the compact rows of the
+    // pruned last layer run unfolded (their residuals were normalised explicitly above).
+    const bool fold_here = fold && (d.pre_ln || !last_pruned);
+    // post-LN fold: ws.h holds x = the PRE-LayerNorm stream of the previous layer's fc2 (LN2 of layer L-1 pending)
+    const bool resid_pending = !d.pre_ln && ln1_folded && !last_pruned;
     {
       GemmArgs g{};
       g.a = ab; g.w = m->gemm_lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
-      if (fold_here) { g.ln_gamma = (const float*)m->lw(L, LTR_WL_LN2_W); g.ln_out = ws.a2; g.ln_stats_out = ws.stats2; g.err_flag = m->err_flag; }
+      // the LayerNorm that follows this residual add: pre-LN blocks LN2 (final_layer_norm), post-LN blocks LN1
+      // (self_attn_layer_norm, opt.py:162-163)
+      if (fold_here) {
+        g.ln_gamma = (const float*)m->lw(L, d.pre_ln ? LTR_WL_LN2_W : LTR_WL_LN1_W);
+        g.ln_out = ws.a2; g.ln_stats_out = ws.stats2; g.err_flag = m->err_flag;
+      }
+      if (resid_pending) {   // residual = LN2 of layer L-1 applied to x, rebuilt in the epilogue
+        g.rln_stats = ws.stats1; g.rln_gamma = (const float*)m->lw(L - 1, LTR_WL_LN2_W);
+        g.rln_beta = (const float*)m->lw(L - 1, LTR_WL_LN2_B); g.rln_parts = H / 64;
+      }
       if ((rc = gemm(g))) return rc;
     }
-    if (!d.pre_ln) {   // 350m: LN after the residual add; h and its operand copy
+    if (!d.pre_ln && !fold_here) {   // 350m: LN after the residual add; h and its operand copy
       rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), hb, ab);
       if (rc) return rc;
     }
@@ -333,15 +353,25 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       if (fold_here) { g.ln_stats_in = ws.stats2; g.ln_c = m->fold_c_fc1[L]; g.bias = m->fold_d_fc1[L]; g.ln_parts = H / 64; }
       if ((rc = gemm(g))) return rc;
     }
-    ln1_folded = fold_here && L + 1 < d.num_layers;   // the next layer's LN1 rides on this fc2
+    // the LayerNorm that follows this residual add rides on fc2: pre-LN blocks the NEXT layer's LN1 (also into the pruned
+    // last layer, whose K | V GEMM consumes it); post-LN blocks this layer's LN2, unless this is the last layer run (its
+    // output must be the true hidden state)
+    ln1_folded = fold_here && (d.pre_ln ? L + 1 < d.num_layers : L + 1 < nl);
     {
       GemmArgs g{};
       g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F; g.a_slab = wd == LTR_W_F16;
-      if (ln1_folded) { g.ln_gamma = (const float*)m->lw(L + 1, LTR_WL_LN1_W); g.ln_out = ws.a; g.ln_stats_out = ws.stats1; g.err_flag = m->err_flag; }
+      if (ln1_folded) {
+        g.ln_gamma = d.pre_ln ? (const float*)m->lw(L + 1, LTR_WL_LN1_W) : (const float*)m->lw(L, LTR_WL_LN2_W);
+        g.ln_out = ws.a; g.ln_stats_out = ws.stats1; g.err_flag = m->err_flag;
+      }
+      if (!d.pre_ln && fold_here) {   // residual = LN1 of this layer applied to out_proj's x
+        g.rln_stats = ws.stats2; g.rln_gamma = (const float*)m->lw(L, LTR_WL_LN1_W);
+        g.rln_beta = (const float*)m->lw(L, LTR_WL_LN1_B); g.rln_parts = H / 64;
+      }
       if ((rc = gemm(g))) return rc;
     }
-    if (!d.pre_ln) {
+    if (!d.pre_ln && !ln1_folded) {
       rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), hb, ab);
       if (rc) return rc;
     }
@@ -508,7 +538,9 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
     // launches: A/B switch for measurements and debugging)
     const char* e = getenv("LTR_NO_LN_FOLD");
     const size_t H = desc->hidden_size, F = desc->ffn_dim;
-    m->ln_fold = desc->weight_dtype == LTR_W_F16 && desc->pre_ln && H % 64 == 0 && desc->num_layers > 0 && !(e && e[0] == '1');
+    // pre-LN (125m): LN1 rides on QKV, LN2 on fc1.  Post-LN (350m): this layer's LN1 (after the attention residual)
+    // rides on fc1, the PREVIOUS layer's LN2 on QKV; the residuals are rebuilt by the RLN epilogue (forward_chunk).
+    m->ln_fold = desc->weight_dtype == LTR_W_F16 && H % 64 == 0 && desc->num_layers > 0 && !(e && e[0] == '1');
     if (m->ln_fold) {
       const size_t per_layer = 2 * (3 * H + F);
       if (hipMalloc((void**)&m->fold, per_layer * desc->num_layers * sizeof(float)) != hipSuccess) {
@@ -518,12 +550,14 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
         float* p = m->fold + (size_t)L * per_layer;
         m->fold_c_qkv.push_back(p); m->fold_d_qkv.push_back(p + 3 * H);
         m->fold_c_fc1.push_back(p + 6 * H); m->fold_d_fc1.push_back(p + 6 * H + F);
-        if ((rc = launch_ln_fold_coeff(m->lw(L, LTR_WL_QKV_W), (const float*)m->lw(L, LTR_WL_LN1_W),
-                                       (const float*)m->lw(L, LTR_WL_LN1_B), (const float*)m->lw(L, LTR_WL_QKV_B),
-                                       (int)(3 * H), (int)H, p, p + 3 * H, cs)) ||
-            (rc = launch_ln_fold_coeff(m->lw(L, LTR_WL_FC1_W), (const float*)m->lw(L, LTR_WL_LN2_W),
-                                       (const float*)m->lw(L, LTR_WL_LN2_B), (const float*)m->lw(L, LTR_WL_FC1_B),
-                                       (int)F, (int)H, p + 6 * H, p + 6 * H + F, cs))) {
+        const bool pre = desc->pre_ln != 0;
+        const int lq = pre ? L : (L > 0 ? L - 1 : 0);      // layer whose LayerNorm feeds this QKV (post-LN layer 0: unused)
+        if ((rc = launch_ln_fold_coeff(m->lw(L, LTR_WL_QKV_W), (const float*)m->lw(lq, pre ? LTR_WL_LN1_W : LTR_WL_LN2_W),
+                                       (const float*)m->lw(lq, pre ? LTR_WL_LN1_B : LTR_WL_LN2_B),
+                                       (const float*)m->lw(L, LTR_WL_QKV_B), (int)(3 * H), (int)H, p, p + 3 * H, cs)) ||
+            (rc = launch_ln_fold_coeff(m->lw(L, LTR_WL_FC1_W), (const float*)m->lw(L, pre ? LTR_WL_LN2_W : LTR_WL_LN1_W),
+                                       (const float*)m->lw(L, pre ? LTR_WL_LN2_B : LTR_WL_LN1_B),
+                                       (const float*)m->lw(L, LTR_WL_FC1_B), (int)F, (int)H, p + 6 * H, p + 6 * H + F, cs))) {
           delete m; return rc;
         }
       }

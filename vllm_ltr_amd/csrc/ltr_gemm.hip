@@ -77,6 +77,11 @@ struct Epilogue {
   const float* ln_c;      // consumer: [N] LN_FOLD_SCALE * sum_k gamma_k W[n, k]   (bias then holds beta W + b)
   int n_part;
   int32_t* err_flag;      // producer: bit 1 is set when |x gamma scale| leaves the fp16 range (ltr_status reports it)
+  // residual = LayerNorm(resid) rebuilt on the fly (post-LN blocks, "RLN" below)
+  const float2* r_stats;  // [r_parts][M] (mean, M2) pieces of the rows of `resid`
+  const float* r_gamma;   // [N]
+  const float* r_beta;    // [N]
+  int r_parts;
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -187,16 +192,62 @@ __device__ unsigned long long g_waits[8192 * 2];
 constexpr float LN_FOLD_SCALE = 16.f;
 enum { LN_NONE = 0, LNP = 1, LNC = 2 };
 
+// (mean, M2) of the 64-column pieces of one row -> (mean, rstd * out_scale).  Shifted-data sums around the first piece's
+// mean (equal counts per piece): the loads of all pieces are independent of each other and fly together (a serial Chan
+// update would put n_part dependent L2 round trips in front of the first barrier of the tile).
+__device__ __forceinline__ float2 combine_row_stats(const float2* __restrict__ sp /*&stats[0][row]*/, int n_part, int M,
+                                                    float out_scale) {
+  const float2 s0 = sp[0];
+  float s1 = 0.f, s2 = 0.f, sm = s0.y;
+  auto add = [&](const float2 s) { const float d = s.x - s0.x; s1 += d; s2 = fmaf(d, d, s2); sm += s.y; };
+  if (n_part == 12) {
+    float2 v[11];
+#pragma unroll
+    for (int p = 0; p < 11; ++p) v[p] = sp[(size_t)(p + 1) * M];
+#pragma unroll
+    for (int p = 0; p < 11; ++p) add(v[p]);
+  } else if (n_part == 16) {
+    float2 v[15];
+#pragma unroll
+    for (int p = 0; p < 15; ++p) v[p] = sp[(size_t)(p + 1) * M];
+#pragma unroll
+    for (int p = 0; p < 15; ++p) add(v[p]);
+  } else {
+#pragma unroll 4
+    for (int p = 1; p < n_part; ++p) add(sp[(size_t)p * M]);
+  }
+  const float np_ = (float)n_part;
+  const float mean = s0.x + s1 / np_;
+  const float m2 = sm + 64.f * fmaxf(s2 - s1 * s1 / np_, 0.f);
+  return make_float2(mean, rsqrtf(m2 / (64.f * np_) + LN_EPS) * out_scale);
+}
+
 // One (row, 8 columns) piece of the epilogue, shared by the large-tile and the small-tile kernel: x = accumulator
 // columns ccol..ccol+3 (va) and ccol_b..ccol_b+3 (vb) of row `grow`; LayerNorm-fold consumer scaling, bias, ReLU,
 // residual, f32 / split stores, LayerNorm-fold producer outputs.  The 8 lanes that hold one row's 64-column piece are
 // consecutive lanes of one wave (lane & 7 = position in the piece); `piece64` = index of that piece in the row.
-template <int LNM>
-__device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, float4 vb, const float4& ra, const float4& rb,
+// RLN (post-LN blocks, LayerNorm fold): `resid` holds the PRE-LayerNorm residual stream x written by the previous
+// producer; the residual to add is y = LN(x) = (x - mean) rstd gamma + beta with (mean, rstd) = rst of the row.
+template <int LNM, bool RLN>
+__device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, float4 vb, float4 ra, float4 rb,
                                                const float4& bias_a, const float4& bias_b, const float4& lnv_a,
-                                               const float4& lnv_b, const float2 st2, int grow, int ccol, int ccol_b,
-                                               size_t o, int M, int lane, int piece64) {
+                                               const float4& lnv_b, const float2 st2, const float2 rst, int grow, int ccol,
+                                               int ccol_b, size_t o, int M, int lane, int piece64) {
+  if (RLN) {   // (the two halves one after the other: the affine vectors of both at once cost 8 more live registers)
+    {
+      const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol);
+      ra.x = (ra.x - rst.x) * rst.y * g.x + b.x; ra.y = (ra.y - rst.x) * rst.y * g.y + b.y;
+      ra.z = (ra.z - rst.x) * rst.y * g.z + b.z; ra.w = (ra.w - rst.x) * rst.y * g.w + b.w;
+    }
+    asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w));      // keep the halves apart in the schedule
+    {
+      const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol_b), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol_b);
+      rb.x = (rb.x - rst.x) * rst.y * g.x + b.x; rb.y = (rb.y - rst.x) * rst.y * g.y + b.y;
+      rb.z = (rb.z - rst.x) * rst.y * g.z + b.z; rb.w = (rb.w - rst.x) * rst.y * g.w + b.w;
+    }
+  }
   if (LNM == LNC) {   // v = (acc - mean c_n) rstd / scale (+ d_n, held in bias)
+    static_assert(!(LNM == LNC && RLN), "consumer epilogue and LayerNorm'd residual never meet");
     va.x = (va.x - st2.x * lnv_a.x) * st2.y; va.y = (va.y - st2.x * lnv_a.y) * st2.y;
     va.z = (va.z - st2.x * lnv_a.z) * st2.y; va.w = (va.w - st2.x * lnv_a.w) * st2.y;
     vb.x = (vb.x - st2.x * lnv_b.x) * st2.y; vb.y = (vb.y - st2.x * lnv_b.y) * st2.y;
@@ -268,12 +319,13 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
   }
 }
 
-template <int LNM>
+template <int LNM, bool RLN>
 __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int tiles_m, int tiles_n, int gm, Epilogue ep) {
   // 64 KiB of stages (+ 1 KiB: (mean, rstd/16) of the tile's 128 rows, LNC).  ONE array on purpose (see above).
-  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE + (LNM == LNC ? 512 : 0)];
+  // (LNC: of the rows of A; RLN: of the rows of the residual - the two never meet in one GEMM)
+  __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE + (LNM == LNC || RLN ? 512 : 0)];
 
 #ifdef LTR_GEMM_TIMELINE
   const unsigned long long tl0 = __builtin_readcyclecounter();
@@ -331,30 +383,11 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   unsigned long long tl_dma = 0, tl_bar = 0;
 #endif
   issue(0, 0);
-  if (LNM == LNC && tid < BM) {
-    // (mean, M2) of the row's 64-column pieces -> (mean, rstd / scale).  Shifted-data sums around the first piece's
-    // mean (equal counts per piece), so the loads of all pieces are independent of each other and fly together:
-    // a serial Chan update would put n_part dependent L2 round trips in front of the first barrier of the tile.
+  if ((LNM == LNC || RLN) && tid < BM) {
     const int row = min(m0 + tid, M - 1);
-    const float2* sp = ep.stats_in + row;
-    const float2 s0 = sp[0];
-    float s1 = 0.f, s2 = 0.f, sm = s0.y;
-    auto add = [&](const float2 s) { const float d = s.x - s0.x; s1 += d; s2 = fmaf(d, d, s2); sm += s.y; };
-    if (ep.n_part == 12) {
-      float2 v[11];
-#pragma unroll
-      for (int p = 0; p < 11; ++p) v[p] = sp[(size_t)(p + 1) * M];
-#pragma unroll
-      for (int p = 0; p < 11; ++p) add(v[p]);
-    } else {
-#pragma unroll 4
-      for (int p = 1; p < ep.n_part; ++p) add(sp[(size_t)p * M]);
-    }
-    const float np_ = (float)ep.n_part;
-    const float mean = s0.x + s1 / np_;
-    const float m2 = sm + 64.f * fmaxf(s2 - s1 * s1 / np_, 0.f);
-    const float rstd = rsqrtf(m2 / (64.f * np_) + LN_EPS);
-    reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] = make_float2(mean, rstd * (1.f / LN_FOLD_SCALE));
+    reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] =
+        RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, M, 1.f)
+            : combine_row_stats(ep.stats_in + row, ep.n_part, M, 1.f / LN_FOLD_SCALE);
   }
   for (int kt = 0; kt < nk; ++kt) {
 #ifdef LTR_GEMM_TIMELINE
@@ -437,7 +470,26 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
       for (int e = 0; e < 4; ++e) s_c[(4 * (lane >> 4) + e) * CLD + j * 16 + (lane & 15)] = acc[st][j][e];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (ccol < N) {
+    if (ccol < N && RLN) {
+      // LayerNorm'd residual: ONE row at a time.  The two-row prefetch of the branch below plus the affine vectors of the
+      // residual's LayerNorm do not fit the 128-VGPR budget of four waves per SIMD: the compiler spilled (also with bias /
+      // gamma fetched at their point of use instead of held in registers: 36 B per lane left), and the spilled LNP + RLN
+      // instance produced NaNs - its inline-asm stores sit behind scratch reloads.
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int srow = it * 8 + erow;
+        const int grow = m0 + wr * 64 + st * 16 + srow;
+        if (grow >= M) continue;
+        const size_t o = (size_t)grow * N + ccol;
+        const float4 va = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
+        const float4 vb = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
+        const float4 ra = *reinterpret_cast<const float4*>(ep.resid + o);
+        const float4 rb = *reinterpret_cast<const float4*>(ep.resid + o + (ecol_b - ecol));
+        const float2 st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[grow - m0];
+        epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
+                                 tn * 4 + wc);
+      }
+    } else     if (ccol < N) {
       float4 va[2], vb[2], ra[2], rb[2];
       size_t o[2];
       int gr[2];
@@ -462,9 +514,9 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
       for (int it = 0; it < 2; ++it) {
         if (!ok[it]) continue;
         float2 st2 = make_float2(0.f, 0.f);
-        if (LNM == LNC) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
-        epilogue_piece<LNM>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, gr[it], ccol, ccol_b,
-                            o[it], M, lane, tn * 4 + wc);
+        if (LNM == LNC || RLN) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
+        epilogue_piece<LNM, RLN>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, st2, gr[it], ccol,
+                                 ccol_b, o[it], M, lane, tn * 4 + wc);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -536,7 +588,7 @@ __device__ __forceinline__ bool xcd_tile(int bid, int tiles_m, int tiles_n, XcdM
   return true;
 }
 
-template <int LNM, int BM_, int BN_, int SSTAGES>
+template <int LNM, bool RLN, int BM_, int BN_, int SSTAGES>
 __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f16s_small_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int tiles_m, int tiles_n, XcdMap xmap, Epilogue ep) {
@@ -591,17 +643,10 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
 #pragma unroll
   for (int st = 0; st < SSTAGES - 1; ++st)
     if (st < nst) issue(st, st);
-  if (LNM == LNC && tid < BM_) {     // (mean, M2) pieces of the row -> (mean, rstd / scale); see the large-tile kernel
+  if ((LNM == LNC || RLN) && tid < BM_) {     // (mean, M2) pieces of the row -> (mean, rstd [/ scale]); see the large-tile kernel
     const int row = min(m0 + tid, M - 1);
-    const float2* sp = ep.stats_in + row;
-    const float2 s0 = sp[0];
-    float s1 = 0.f, s2 = 0.f, sm = s0.y;
-#pragma unroll 4
-    for (int p = 1; p < ep.n_part; ++p) { const float2 v = sp[(size_t)p * M]; const float d = v.x - s0.x; s1 += d; s2 = fmaf(d, d, s2); sm += v.y; }
-    const float np_ = (float)ep.n_part;
-    const float mean = s0.x + s1 / np_;
-    const float m2 = sm + 64.f * fmaxf(s2 - s1 * s1 / np_, 0.f);
-    s_stat[tid] = make_float2(mean, rsqrtf(m2 / (64.f * np_) + LN_EPS) * (1.f / LN_FOLD_SCALE));
+    s_stat[tid] = RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, M, 1.f)
+                      : combine_row_stats(ep.stats_in + row, ep.n_part, M, 1.f / LN_FOLD_SCALE);
   }
   for (int kt = 0; kt < nst; ++kt) {
     // stage kt has landed once at most the younger stages' pieces (4 per stage and wave) are outstanding
@@ -693,8 +738,9 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
       }
     }
     float2 st2 = make_float2(0.f, 0.f);
-    if (LNM == LNC) st2 = s_stat[srow];
-    epilogue_piece<LNM>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, grow, ccol, ccol_b, o, M, lane, tn * P64 + pc);
+    if (LNM == LNC || RLN) st2 = s_stat[srow];
+    epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
+                             tn * P64 + pc);
   }
 }
 
@@ -847,8 +893,15 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
-              g.ln_parts, g.err_flag};
+              g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : LN_NONE);
+  const bool rln = g.rln_stats != nullptr;
+  if (rln && (wdtype != LTR_W_F16 || lnm == LNC || !g.resid || !g.rln_gamma || !g.rln_beta || g.rln_parts * 64 != g.N ||
+              g.rln_stats == g.ln_stats_out)) {
+    set_error("gemm: a LayerNorm'd residual needs F16 mode, resid, gamma / beta [N], N / 64 statistics pieces distinct from the "
+              "producer's output and no consumer epilogue");
+    return LTR_E_INVAL;
+  }
   if (lnm != LN_NONE) {
     if (wdtype != LTR_W_F16) { set_error("gemm: the LayerNorm fold exists in F16 mode only"); return LTR_E_INVAL; }
     if (lnm == LNP && (g.out_split.hi || !g.out_f32 || !g.ln_out.hi || !g.ln_stats_out || g.N % 64)) {
@@ -878,7 +931,6 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     static const int small_m = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 1024; }();
     static const int mid_m = [] { const char* e = getenv("LTR_GEMM_MID_M"); return e ? atoi(e) : 3072; }();
     static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 0; }();
-    static const int deep = [] { const char* e = getenv("LTR_GEMM_SMALL_DEEP"); return e ? atoi(e) : 0; }();
     if (g.K % SKS == 0 && (g.M <= small_m || g.M <= mid_m)) {
       const bool sm = g.M <= small_m;
       const int bm = sm ? 32 : 64, bnn = sm ? 64 : 128;
@@ -897,43 +949,41 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
           xm.per_xcd = a * b;                                          // range 0 is never the shorter one
         }
         dim3 sgrid(xm.per_xcd * NXCD);
-#define LTR_SMALL_LAUNCH(LN, BMv, BNv, STv)                                                                                \
+#define LTR_SMALL_LAUNCH(LN, RL, BMv, BNv, STv)                                                                            \
   do {                                                                                                                     \
     typedef SmallCfg<BMv, BNv, STv> Cfg;                                                                                   \
     static const bool attr_ok = [] {                                                                                       \
-      return hipFuncSetAttribute((const void*)gemm_f16s_small_kernel<LN, BMv, BNv, STv>,                                   \
+      return hipFuncSetAttribute((const void*)gemm_f16s_small_kernel<LN, RL, BMv, BNv, STv>,                               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) == hipSuccess;           \
     }();                                                                                                                   \
     (void)attr_ok;                                                                                                         \
-    gemm_f16s_small_kernel<LN, BMv, BNv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(                                  \
+    gemm_f16s_small_kernel<LN, RL, BMv, BNv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(                              \
         (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, g.K, tm_, tn_, xm, ep);                \
   } while (0)
 #define LTR_SMALL_LN(BMv, BNv, STv)                                                                                        \
   do {                                                                                                                     \
-    if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, BMv, BNv, STv); else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, BMv, BNv, STv);       \
-    else LTR_SMALL_LAUNCH(LN_NONE, BMv, BNv, STv);                                                                         \
+    if (rln) { if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, true, BMv, BNv, STv); else LTR_SMALL_LAUNCH(LN_NONE, true, BMv, BNv, STv); } \
+    else if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, false, BMv, BNv, STv);                                                      \
+    else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, false, BMv, BNv, STv);                                                      \
+    else LTR_SMALL_LAUNCH(LN_NONE, false, BMv, BNv, STv);                                                                  \
   } while (0)
-        if (sm) {
-          // at most one workgroup per CU anyway: spend the LDS on a ring of eight (7 stages = 112 KB in flight per CU)
-          if (deep && tm_ * tn_ <= 256) LTR_SMALL_LN(32, 64, 8); else LTR_SMALL_LN(32, 64, 4);
-        } else {
-          LTR_SMALL_LN(64, 128, 4);
-        }
+        // (a ring of eight stages for grids of at most one workgroup per CU was measured and is slower: fc2 of a
+        // one-request call 21.7 vs 15.7 us, profiles/r03_small_batch.txt)
+        if (sm) LTR_SMALL_LN(32, 64, 4); else LTR_SMALL_LN(64, 128, 4);
 #undef LTR_SMALL_LN
 #undef LTR_SMALL_LAUNCH
         LTR_LAUNCH_CHECK();
         return LTR_OK;
       }
     }
-    if (lnm == LNP)
-      gemm_f16s_kernel<LNP><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
-                                                 g.N, g.K, tiles_m, tiles_n, gm, ep);
-    else if (lnm == LNC)
-      gemm_f16s_kernel<LNC><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
-                                                 g.N, g.K, tiles_m, tiles_n, gm, ep);
-    else
-      gemm_f16s_kernel<LN_NONE><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M,
-                                                     g.N, g.K, tiles_m, tiles_n, gm, ep);
+#define LTR_BIG_LAUNCH(LN, RL)                                                                                             \
+  gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, \
+                                                g.K, tiles_m, tiles_n, gm, ep)
+    if (rln) { if (lnm == LNP) LTR_BIG_LAUNCH(LNP, true); else LTR_BIG_LAUNCH(LN_NONE, true); }
+    else if (lnm == LNP) LTR_BIG_LAUNCH(LNP, false);
+    else if (lnm == LNC) LTR_BIG_LAUNCH(LNC, false);
+    else LTR_BIG_LAUNCH(LN_NONE, false);
+#undef LTR_BIG_LAUNCH
   } else {
     gemm_f32_kernel<<<grid, 256, 0, s>>>((const float*)g.a.hi, (const float*)g.w, g.M, g.N, g.K, tiles_m, tiles_n,
                                          ep);

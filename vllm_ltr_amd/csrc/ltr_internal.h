@@ -70,6 +70,12 @@ struct GemmArgs {
   const float* ln_c = nullptr;       // [N] 16 * sum_k gamma_k W[n, k]; `bias` must then hold sum_k beta_k W[n, k] + b_n
   int ln_parts = 0;                  // K / 64
   int32_t* err_flag = nullptr;       // producer: device status word (bit 1 = operand left the fp16 range)
+  // Post-LN blocks with the fold: `resid` holds the PRE-LayerNorm stream x of the previous producer and the residual to
+  // add is LayerNorm(x), rebuilt in the epilogue from x, the row statistics pieces and the affine terms (F16 mode).
+  const void* rln_stats = nullptr;   // float2 [N / 64][M]; non-null selects it
+  const float* rln_gamma = nullptr;  // [N]
+  const float* rln_beta = nullptr;   // [N]
+  int rln_parts = 0;                 // N / 64
 };
 
 // launchers (each in its own .hip file)
