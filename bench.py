@@ -210,6 +210,41 @@ def run_trace(args, spec, ckpt, dev):
     print(json.dumps(out))
 
 
+def run_train(args, spec, ckpt, dev):
+    """the fine-tuning step (train/trainer.py:137-165: forward, listMLE, backward, Adam) on a slate of
+    ``--train-slate`` prompts of the bench length profile (train.sh: --batch-size 32)."""
+    from vllm_ltr_amd.trainer import HipPredictorTrainer
+    n = args.train_slate
+    ids, cu, lens = synthetic_queue(spec, n, seed=0, profile=args.profile)
+    labels = np.random.RandomState(1).permutation(n).astype(np.float32)
+    sh = np.random.RandomState(2).permutation(n)
+
+    def timed(precision):
+        tr = HipPredictorTrainer(spec, ckpt, str(dev), lr=2e-5, weight_decay=0.01, loss="listMLE", precision=precision)
+        for _ in range(args.warmup):
+            tr.step(ids, cu, labels, shuffle=sh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = tr.step(ids, cu, labels, shuffle=sh)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        tr.close()
+        return dt, loss
+    dt32, _ = timed("f32")          # round 2's arithmetic: every GEMM on the exact-f32 MFMA, f32 VALU attention
+    dt, loss = timed("split")
+    lin, att = model_flops(spec, lens)
+    out = {"metric": "fine-tuning step of the predictor (forward + listMLE + backward + Adam), tokens/s",
+           "value": float(cu[-1]) / dt, "unit": "tokens/s", "higher_is_better": True, "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3,
+           "dtype": "f32 master weights / activations / gradients; GEMMs split-fp16 x split-fp16 MFMA (4 passes), f32 accumulate",
+           "exact_f32_ms_per_step": dt32 * 1e3, "speedup_vs_exact_f32": dt32 / dt,
+           "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths)",
+           "config": {"workload": f"OPT-{args.model} predictor, slate of {n} prompts ({int(cu[-1])} tokens), listMLE, Adam"},
+           "algorithmic_tflops": 3.0 * (lin + att) / dt / 1e12, "loss": loss}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +275,8 @@ def main():
                     help="skip the class-mode head measurement (8,192 requests x 8,192 labels, kernels.class_head)")
     ap.add_argument("--sweep", action="store_true", help="extra JSON line: cold call at 256 ... 64k requests")
     ap.add_argument("--trace", default=None, choices=["burst", "gamma"], help="config 5 ranker-side trace replay")
+    ap.add_argument("--train", action="store_true", help="time the fine-tuning step instead (SURVEY 8f-4)")
+    ap.add_argument("--train-slate", type=int, default=32)
     ap.add_argument("--trace-requests", type=int, default=2000)
     ap.add_argument("--trace-rate", type=float, default=16.0)
     ap.add_argument("--trace-cv", type=float, default=1.0)
@@ -273,6 +310,8 @@ def main():
     ckpt = seeded_checkpoint(spec, 0)
     if args.trace:
         return run_trace(args, spec, ckpt, dev)
+    if args.train:
+        return run_train(args, spec, ckpt, dev)
     scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)
 
     strong = args.queue_total > 0

@@ -332,7 +332,10 @@ int ltr_listmle(const float* y_pred, const float* y_true, const int32_t* shuffle
  * train/trainer.py:122-165 - forward of the OPTForSequenceClassification predictor on a slate of prompts
  * (prefill_predictor.py:76-79), loss_func(outputs.view(1, -1), labels) with listMLE / MSELoss or CrossEntropyLoss over
  * num_labels classes (:125-157), loss.backward(), torch.optim.Adam(lr, weight_decay).step() (:122,161-165: L2 decay added
- * to the gradient, bias-corrected moments), optimizer.zero_grad().  All arithmetic is f32 (fp32 master weights, :99-101).
+ * to the gradient, bias-corrected moments), optimizer.zero_grad().  Parameters, activations, gradients and moments are f32
+ * (fp32 master weights, :99-101); the dense layers multiply on the fp16 matrix cores with both operands split into two
+ * fp16 terms (f32-grade products, f32 accumulation; LTR_TRAIN_F32=1 in the environment of ltr_train_create selects the
+ * exact-f32 MFMA instead).
  * ltr_train_create COPIES the f32 weights (same pointer order as ltr_create, every tensor f32) into library-owned
  * parameter / gradient / moment buffers; ltr_train_read copies the current value of a tensor out, for evaluation and
  * for writing the fine-tuned checkpoint (trainer.py:213-216 saves it .half()). */
@@ -357,7 +360,9 @@ size_t ltr_train_workspace_bytes(ltr_train_handle h, int64_t N, int64_t T);
 /* One step on a slate of N prompts (flat ids / cu_seqlens as ltr_score; the whole slate is one pass).
  *   labels   f32 [N]: listMLE / mse targets, or class indices for crossentropy
  *   shuffle  int32 [N]: the random permutation of listMLE.py:33 (listMLE only)
- *   apply_update 0: gradients only (ltr_train_grad), no Adam step
+ *   apply_update 1: the full step; 0: gradients only, no Adam step; -1: evaluation forward (predictor.model.eval(),
+ *            trainer.py:171-190: no dropout, no loss, no backward - labels / shuffle / loss_out may be NULL, logits_out is
+ *            the result)
  *   loss_out f32 [1] (device); logits_out f32 [N, num_labels] or NULL: the outputs BEFORE the update */
 int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
                    const int32_t* cu_seqlens_host, int32_t N, int32_t T, const float* labels,

@@ -1,5 +1,8 @@
-O=gpurun_out/r03_j; mkdir -p $O
-python -m pytest tests -m gpu -x -q > $O/full.log 2>&1; tail -5 $O/full.log
-python bench.py --model 350m --profile lmsys --no-cpu-baseline --no-strong --no-class-head --steps 3 --warmup 1 > $O/bench_config3.json 2>> $O/bench.err; python -c "
-import json
-d=json.loads(open('$O/bench_config3.json').read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],1), d['p50_steady_new_latency_ms'], {k:(round(v.get('ms_per_step') or 0,2), v.get('launches_per_step')) for k,v in d['kernels'].items()}, d['roofline']['unfused'])"
+O=gpurun_out/r03_k; mkdir -p $O
+python -m pytest tests/test_train_step.py -m gpu -q -s > $O/t_train.log 2>&1; grep -E "^FAILED|fit:|passed|failed|AssertionError|ListMLE" $O/t_train.log | tail -12
+for f in 1 0; do LTR_TRAIN_F32=$f python bench.py --train --steps 3 --warmup 1 2>/dev/null | tee -a $O/train_bench.jsonl | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('F32=$f', round(d['ms_per_step'],1),'ms', round(d['value']), 'tok/s', round(d['algorithmic_tflops'],1), 'TFLOP/s')"; done
+for n in 64 128; do LTR_TRAIN_F32=0 python bench.py --train --train-slate $n --steps 3 --warmup 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('slate $n', round(d['ms_per_step'],1),'ms', round(d['value']), 'tok/s', round(d['algorithmic_tflops'],1), 'TFLOP/s')"; done

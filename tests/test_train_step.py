@@ -94,14 +94,15 @@ def _grad_close(got, want, name, gmax, rel=2e-4):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split", "f32"])
 @pytest.mark.parametrize("case", CASES)
-def test_hip_training_steps_match_hf_plus_adam(case):
+def test_hip_training_steps_match_hf_plus_adam(case, precision):
     """ltr_train_step (forward, loss, backward, Adam) replays the HF + reference-listMLE + torch-Adam steps: losses,
     logits, first-step gradients (also against the oracle's full gradient set) and the updated weights."""
     from vllm_ltr_amd.trainer import HipPredictorTrainer
     z, spec, loss_name, lr, wd, n_steps = _load(case)
     ckpt = seeded_checkpoint(spec, int(z["seed"]))
-    tr = HipPredictorTrainer(spec, ckpt, "cuda:0", lr=lr, weight_decay=wd, loss=loss_name)
+    tr = HipPredictorTrainer(spec, ckpt, "cuda:0", lr=lr, weight_decay=wd, loss=loss_name, precision=precision)
     orc = OracleTrainer(spec, ckpt, lr=lr, weight_decay=wd, loss=loss_name)
     for st in range(n_steps):
         args = (z[f"s{st}_ids"], z[f"s{st}_cu"], z[f"s{st}_labels"], z[f"s{st}_shuffle"])
@@ -210,8 +211,36 @@ def test_hip_trainer_learns_and_round_trips_through_the_serving_path(tmp_path):
 
 
 @pytest.mark.gpu
+def test_fit_loop_with_kendall_tau_and_refused_losses():
+    """fit() = the loop of train/trainer.py:134-200: shuffled slates per epoch, then the evaluation pass (eval-mode
+    forward, Kendall's tau of the predictions against the labels, :195).  neuralNDCG (:127) is refused by name."""
+    from vllm_ltr_amd.opt_spec import OPTSpec
+    from vllm_ltr_amd.trainer import HipPredictorTrainer, len2label
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 78)
+    with pytest.raises(NotImplementedError, match="neuralNDCG"):
+        HipPredictorTrainer(spec, ckpt, "cuda:0", loss="neuralNDCG")
+    r = np.random.RandomState(0)
+
+    def example():
+        key = int(r.randint(4, 36))
+        return [2, key] + r.randint(40, spec.vocab_size, r.randint(2, 30)).tolist(), float(len2label(key * 20, 1024, 1))
+    train = [example() for _ in range(64 * 20)]
+    test = [example() for _ in range(200)]
+    tr = HipPredictorTrainer(spec, ckpt, "cuda:0", lr=2e-3, weight_decay=0.01, loss="listMLE", dropout=0.1, seed=42)
+    hist = tr.fit(train, test, epochs=3, batch_size=64, log=None)
+    print("fit:", [(h["epoch"], round(h["loss"], 3), round(h["kendall_tau"], 3)) for h in hist])
+    assert len(hist) == 3 and hist[-1]["loss"] < hist[0]["loss"] and hist[-1]["kendall_tau"] > 0.5
+    # eval forward == the scoring path on the same (.half()-exact here? no: f32 master weights) - so only self-consistency:
+    ids = np.array(test[0][0], np.int64); cu = np.array([0, len(ids)], np.int32)
+    a, b = tr.predict(ids, cu), tr.predict(ids, cu)
+    assert np.array_equal(a, b) and a.shape == (1, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split", "f32"])
 @pytest.mark.parametrize("model,layers", [("125m", 1), ("350m", 1), ("125m", 12), ("350m", 24)])
-def test_hip_training_step_at_true_shapes(model, layers):
+def test_hip_training_step_at_true_shapes(model, layers, precision):
     """One ListMLE step at the true OPT-125m / OPT-350m widths (the shapes the reference fine-tunes, train/train.sh)
     against the oracle's autograd in f64: loss, logits and the gradient of every parameter tensor.
 
@@ -235,7 +264,7 @@ def test_hip_training_step_at_true_shapes(model, layers):
     shuffle = r.permutation(len(lens)).astype(np.int32)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     want_loss, want_logits, og = OracleTrainer(spec, ckpt, loss="listMLE", dtype=torch.float64).step(ids, cu, labels, shuffle, apply=False)
-    tr = HipPredictorTrainer(spec, ckpt, "cuda:0", loss="listMLE")
+    tr = HipPredictorTrainer(spec, ckpt, "cuda:0", loss="listMLE", precision=precision)
     loss, logits = tr.step(ids, cu, labels, shuffle, apply_update=False, return_logits=True)
     assert abs(loss - want_loss) <= 2e-5 * max(1.0, abs(want_loss)), (loss, want_loss)
     np.testing.assert_allclose(logits, want_logits, atol=3e-5, rtol=0)
@@ -249,7 +278,10 @@ def test_hip_training_step_at_true_shapes(model, layers):
             assert float(np.abs(g[name]).max()) <= 1e-5 * gmax, name
             continue
         rel = np.abs(g[name] - w) / float(np.abs(w).max())
-        assert rel.max() <= 6e-2, f"{name}: {rel.max():.2e}"
+        # worst single entry: at one layer nothing flips (6e-2 is generous); at full depth it is ONE ReLU flip's row
+        # contribution - which unit flips is decided by rounding noise, i.e. differs between the f32 and the split-fp16
+        # GEMMs (seen: 6e-2 class with f32, 1.5e-1 with split on the same inputs); the count bound below is the real check
+        assert rel.max() <= (6e-2 if layers == 1 or precision == "f32" else 0.25), f"{name}: {rel.max():.2e}"
         assert np.median(rel) <= med_bar, f"{name}: median {np.median(rel):.2e}"
         n_out += int((rel > 1e-2).sum()); n_all += rel.size
         worst, worst_med = max(worst, float(rel.max())), max(worst_med, float(np.median(rel)))

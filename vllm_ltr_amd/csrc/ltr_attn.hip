@@ -226,7 +226,8 @@ template <int NW>
 __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
     const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
-    __half* __restrict__ out_hi, __half* __restrict__ out_lo) {
+    __half* __restrict__ out_hi, __half* __restrict__ out_lo,
+    float* __restrict__ lse2 /*nullable: [T, heads] m + log2(l) of every query row (training)*/) {
   // 48 KiB ring, tiles it+1 and it+2 in flight.  Dynamic LDS on purpose: with a static array hipcc tracks the
   // LDS-DMA stores against every ds_read and drains vmcnt(0) in front of the first fragment read
   extern __shared__ __attribute__((aligned(16))) __half smem[];
@@ -383,6 +384,9 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   if (!wave_active) return;
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
+  // training: the backward recomputes the softmax from the log-sum-exp of the row (log2 domain, like the f32 kernel;
+  // m may lag the true maximum by the deferral threshold, m + log2(l) does not)
+  if (lse2 != nullptr && lh == 0 && q0 + lq < L) lse2[(size_t)(t0 + q0 + lq) * (H / D) + head] = m + log2f(l);
   constexpr int OPITCH = 136;                           // bytes
   char* s_o = reinterpret_cast<char*>(smem) + wave * (2 * 32 * OPITCH);
 #pragma unroll
@@ -531,6 +535,15 @@ __global__ void __launch_bounds__(LQ_WAVES * 64) attn_lastq_kernel(const float* 
 
 }  // namespace
 
+// the work list of `qb`-query blocks alone (the training backward walks 64-query blocks whatever kernel ran the forward)
+int launch_attention_blocks(const int32_t* cu, int n_req, int qb, int32_t* blk_start, hipStream_t s) {
+  if (n_req == 0) return LTR_OK;
+  int4* blk_desc = reinterpret_cast<int4*>(blk_start + ((n_req + 1 + 3) & ~3));
+  attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, qb, blk_start, blk_desc);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
                      int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2) {
   if (n_req == 0 || T == 0) return LTR_OK;
@@ -546,7 +559,7 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
     }
     dim3 grid(T / (32 * NW) + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
     attn_f16s_kernel<NW><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
-                                                  n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo);
+                                                  n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
   } else {
     if (build_blocks) {
       attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start, blk_desc);

@@ -105,7 +105,10 @@ int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req,
                      int T, int H, int n_heads, int32_t* blk_start /*scratch: (n_req+4)*4 + (T/64+n_req+1)*16 bytes*/, AOp out,
                      int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s,
-                     float* lse2 = nullptr /*F32 mode: [T, heads] log2-domain log-sum-exp of every query row (training)*/);
+                     float* lse2 = nullptr /*[T, heads] log2-domain log-sum-exp of every query row (training), nullable*/);
+
+int launch_attention_blocks(const int32_t* cu /*chunk-local, [n+1]*/, int n_req, int qb /*queries per block*/,
+                            int32_t* blk_start /*scratch as in launch_attention*/, hipStream_t s);
 
 // F16 mode, last layer of a scoring call: attention of the LAST query of every request only.  q f32 [n_req, H]
 // (unscaled), kv = hi|lo planes [T, 2H] (k | v), out = row-major hi|lo planes [n_req, H]

@@ -5,10 +5,13 @@
 // `loss_func(outputs.view(1, -1), labels)` with listMLE / MSELoss, or CrossEntropyLoss over num_labels classes
 // (:125-157), `loss.backward()`, `torch.optim.Adam(lr, weight_decay).step()` (:122,161-165).
 //
-// Everything is f32 (the reference computes the forward under autocast = fp16 on its GPU; f32 is at least that
-// precise, and what the CPU oracle - torch autograd over the scorer's arithmetic - computes).  The dense layers run on
-// the exact-f32 MFMA GEMM (gemm_f32_kernel, C = A B^T); the backward's dX = dY W and dW = dY^T X are brought to that
-// form with explicit transposes.  Attention, LayerNorm, ReLU, losses, Adam: VALU kernels below.  Training batches are
+// Parameters, activations, gradients and the optimiser state are f32 (the reference computes the forward under autocast
+// = fp16 on its GPU; this is at least that precise, and the CPU oracle - torch autograd over the scorer's arithmetic -
+// is f32).  The dense layers C = A B^T run on the fp16 matrix cores with BOTH operands split into two fp16 terms
+// (A = Ah + Al, B = Bh + Bl, ~22 significant bits each; products exact, f32 accumulation): [A | A] [Bh | Bl]^T over a
+// doubled K is ONE launch of the scoring path's split-fp16 GEMM (ltr_gemm.hip) = four fp16 MFMA passes instead of the
+// 16x slower exact-f32 MFMA (gemm_f32_kernel; LTR_TRAIN_F32=1, and shapes the fp16 kernel does not take, keep it).  The
+// backward's dX = dY W and dW = dY^T X are brought to the C = A B^T form with explicit transposes.  Attention, LayerNorm, ReLU, losses, Adam: VALU kernels below.  Training batches are
 // slates of tens of prompts (trainer.py --batch-size 64), so this file is written for clarity and exactness, not for
 // the ranking path's throughput.
 //
@@ -52,23 +55,154 @@ __global__ void __launch_bounds__(256) transpose_pad_kernel(const float* __restr
   }
 }
 
-// column sums in two fixed-order stages: partial[b][c] = sum over rows [b * 256, ...) ; out[c] = sum_b partial[b][c]
+// max |x| of a tensor into *slot (non-negative floats order like their bit patterns; the slot is zeroed per step)
+__global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ slot) {
+  float m = 0.f;
+  const size_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+  m = wave_max(m);
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+  }
+}
+// Power-of-two scale that brings a tensor of magnitude amax to ~2^12 before it is split into fp16 hi + lo: gradients
+// are 1e-3 ... 1e-9 in magnitude, far below fp16's normal range (6e-5), where hi would be a subnormal and lo flush to
+// zero - the split would silently degrade to a few bits.  Scaling by 2^k is exact and is undone (exactly) by
+// gemm_finish_kernel.  Elements down to 2^-15 of the tensor's maximum keep all 22 bits.
+__device__ __forceinline__ float split_scale(float amax) {
+  return amax > 0.f && amax < INFINITY ? ldexpf(1.f, 12 - ilogbf(amax)) : 1.f;
+}
+
+// f32 B [N, K] -> the split-fp16 GEMM's slab-major weight image of [Bh | Bl] ([N, 2K] with hi(B) in the first K
+// columns and lo(B) = fp16(B - hi) in the last K): element (n, k') at ((k' >> 5) * N + n) * 32 + (k' & 31).  One 16-byte
+// piece (8 halves) per thread.
+__global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict__ B, __half* __restrict__ dst, int N, int K,
+                                                         const float* __restrict__ amax) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // piece index in the destination
+  const size_t pieces = (size_t)N * K / 4;                          // 2K halves per row / 8
+  if (i >= pieces) return;
+  const int c = (int)(i & 3);
+  const size_t rn = i >> 2;                                         // slab * N + n
+  const int n = (int)(rn % N), slab = (int)(rn / N);
+  const int nslab = K / 32;
+  const bool lo = slab >= nslab;
+  const float* src = B + (size_t)n * K + (lo ? slab - nslab : slab) * 32 + c * 8;
+  const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+  const float sc = split_scale(*amax);
+  const float x[8] = {v0.x * sc, v0.y * sc, v0.z * sc, v0.w * sc, v1.x * sc, v1.y * sc, v1.z * sc, v1.w * sc};
+  __half o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { __half h, l; split_f16(x[e], h, l); o[e] = lo ? l : h; }
+  *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(o);
+}
+
+// f32 A [M, K] -> the split-fp16 GEMM's slab-major operand planes of [A | A] (K' = 2K): hi' / lo' [2K / 32][M][32], the
+// K / 32 slabs of A twice.  One 16-byte piece (8 halves) per thread and plane copy.
+__global__ void __launch_bounds__(256) split_operand_dup_kernel(const float* __restrict__ A, __half* __restrict__ hi,
+                                                                __half* __restrict__ lo, int M, int K,
+                                                                const float* __restrict__ amax) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // piece of the first copy: (slab * M + row) * 4 + chunk
+  const size_t pieces = (size_t)M * K / 8;
+  if (i >= pieces) return;
+  const int c = (int)(i & 3);
+  const size_t sr = i >> 2;
+  const int row = (int)(sr % M), slab = (int)(sr / M);
+  const float* src = A + (size_t)row * K + slab * 32 + c * 8;
+  const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+  const float sc = split_scale(*amax);
+  const float x[8] = {v0.x * sc, v0.y * sc, v0.z * sc, v0.w * sc, v1.x * sc, v1.y * sc, v1.z * sc, v1.w * sc};
+  __half h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
+  const size_t second = (size_t)M * K;                              // halves per copy
+  *reinterpret_cast<uint4*>(hi + i * 8) = *reinterpret_cast<const uint4*>(h);
+  *reinterpret_cast<uint4*>(hi + second + i * 8) = *reinterpret_cast<const uint4*>(h);
+  *reinterpret_cast<uint4*>(lo + i * 8) = *reinterpret_cast<const uint4*>(l);
+  *reinterpret_cast<uint4*>(lo + second + i * 8) = *reinterpret_cast<const uint4*>(l);
+}
+
+// out = (ReLU)(raw / (sa sb) + bias) + resid: undoes the operand scales of the split GEMM (exact powers of two) and
+// applies what the f32 GEMM's epilogue applies; optionally also writes the result as row-major hi | lo planes (QKV for
+// the MFMA attention).  8 consecutive columns per thread.
+__global__ void __launch_bounds__(256) gemm_finish_kernel(const float* __restrict__ raw, const float* __restrict__ amax2,
+                                                          const float* __restrict__ bias, const float* resid, float* out,
+                                                          size_t n8, int N, int relu, __half* __restrict__ p_hi,
+                                                          __half* __restrict__ p_lo) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float inv = 1.f / (split_scale(amax2[0]) * split_scale(amax2[1]));
+  const int col = (int)((i * 8) % N);
+  float v[8];
+  *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(raw + i * 8);
+  *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(raw + i * 8 + 4);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = v[e] * inv + (bias ? bias[col + e] : 0.f);
+    if (relu) x = fmaxf(x, 0.f);
+    if (resid) x += resid[i * 8 + e];
+    v[e] = x;
+  }
+  *reinterpret_cast<float4*>(out + i * 8) = *reinterpret_cast<const float4*>(v);
+  *reinterpret_cast<float4*>(out + i * 8 + 4) = *reinterpret_cast<const float4*>(v + 4);
+  if (p_hi) {
+    __half h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_f16(v[e], h[e], l[e]);
+    *reinterpret_cast<uint4*>(p_hi + i * 8) = *reinterpret_cast<const uint4*>(h);
+    *reinterpret_cast<uint4*>(p_lo + i * 8) = *reinterpret_cast<const uint4*>(l);
+  }
+}
+
+// hi | lo fp16 planes -> f32 (the MFMA attention's output for the saved activations)
+__global__ void __launch_bounds__(256) planes_to_f32_kernel(const __half* __restrict__ hi, const __half* __restrict__ lo,
+                                                            float* __restrict__ out, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 a = *reinterpret_cast<const uint4*>(hi + i * 8), b = *reinterpret_cast<const uint4*>(lo + i * 8);
+  const __half* ah = reinterpret_cast<const __half*>(&a);
+  const __half* bl = reinterpret_cast<const __half*>(&b);
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = __half2float(ah[e]) + __half2float(bl[e]);
+  *reinterpret_cast<float4*>(out + i * 8) = *reinterpret_cast<const float4*>(o);
+  *reinterpret_cast<float4*>(out + i * 8 + 4) = *reinterpret_cast<const float4*>(o + 4);
+}
+
+// column sums in two fixed-order stages: partial[b][c] = sum over rows [b * CS_ROWS, ...) ; out[c] = sum_b partial[b][c]
+// (32-row blocks: a slate is a few thousand rows, 256-row blocks left the chip to 12 x 16 workgroups: 71 us per call, 98
+// calls per step)
+constexpr int CS_ROWS = 32;
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y /*nullable: sums x*y*/,
                                                              int M, int N, float* __restrict__ partial) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= N) return;
-  const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
   float s = 0.f;
+#pragma unroll 8
   for (int r = r0; r < r1; ++r) s += y ? x[(size_t)r * N + c] * y[(size_t)r * N + c] : x[(size_t)r * N + c];
   partial[(size_t)blockIdx.y * N + c] = s;
 }
+// (64 columns per workgroup, the partials of a column dealt round-robin to the four waves and added up in a fixed order)
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nb, int N,
                                                            float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += partial[(size_t)b * N + c];
-  out[c] = s;
+  if (c < N)
+    for (int b = wave; b < nb; b += 4) s += partial[(size_t)b * N + c];
+  sm[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < N) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 // LayerNorm backward, one wave per row: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;
@@ -388,6 +522,7 @@ struct ltr_trainer {
   int device = 0;
   int64_t step = 0;                    // forward/backward passes so far (seeds the dropout masks)
   int64_t adam_step = 0;               // optimizer.step() calls so far: torch.optim.Adam advances t only there
+  bool use_f32 = false;                // LTR_TRAIN_F32=1: every GEMM on the exact-f32 MFMA kernel
   size_t total = 0;
   std::vector<size_t> off, cnt;        // per weight index (ltr_create's index space)
   float *P = nullptr, *G = nullptr, *M1 = nullptr, *V1 = nullptr, *wT = nullptr;
@@ -433,18 +568,23 @@ size_t weight_count(const ltr_model_desc& d, int idx) {
 }
 
 // workspace carve-up of one step
+constexpr int MAX_GEMMS = 4096;      // split GEMMs per step (a 24-layer model makes ~290)
 struct TrainWs {
   struct Layer { float *x0, *n1, *qkv, *ao, *lse, *mid, *n2, *f, *ao_raw, *mlp_raw; };
   std::vector<Layer> L;
   float *tok, *hfin, *hl, *z, *y, *logits, *dlogits, *row_loss, *dy, *dz, *dhl;
   float *dh, *dbig, *dsmall, *dsmall2, *xhd, *t1, *t2, *partial, *Dq;
+  float *opa, *wb;         // split-fp16 GEMM operands of one call: A image hi|lo over 2K, [Bh | Bl] weight image
+  float *qkvp, *aop;       // hi | lo planes of qkv [2][T, 3H] and of the attention output [2][T, H] (fp16 path)
+  float *gtmp, *scales;    // raw (scaled) product of a split GEMM; max |x| of the operands of every GEMM of the step
   int32_t* blk;
+  int32_t* blk2;     // work list of the MFMA attention forward (fp16 path)
   size_t bytes;
 };
 
 TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, bool dropout) {
   const size_t H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, nh = d.num_heads, nl = d.num_labels;
-  const size_t Tp = (T + 15) / 16 * 16, Np = (N + 15) / 16 * 16;
+  const size_t Tp = (T + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
   const size_t big = std::max<size_t>(3 * H, F);
   char* p = (char*)base;
   size_t o = 0;
@@ -461,9 +601,14 @@ TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, b
   w.row_loss = take(N + 8); w.dy = take(Np * De); w.dz = take(Np * H); w.dhl = take(Np * H);
   w.dh = take(T * H); w.dbig = take(T * big); w.dsmall = take(T * H); w.dsmall2 = take(T * H); w.xhd = take(T * H);
   w.t1 = take(big * Tp); w.t2 = take(big * Tp);
-  w.partial = take(((size_t)(T + 255) / 256 + 1) * big);
+  w.qkvp = take(T * 3 * H + 64); w.aop = take(T * H + 64);           // 2 planes x 2 B = one float per element
+  w.gtmp = take(std::max(big * Tp, F * H) + 64); w.scales = take(MAX_GEMMS * 2);
+  w.opa = take(2 * big * Tp + 64);                                   // 2 planes x M x 2K halves = 2 M K floats
+  w.wb = take(std::max(std::max(big * Tp, big * H), F * H) + 64);    // N x 2K halves = N K floats
+  w.partial = take(((size_t)(T + CS_ROWS - 1) / CS_ROWS + 1) * big);
   w.Dq = take(T * nh);
   w.blk = (int32_t*)take((N + 4) + (T / 64 + N + 1) * 4);
+  w.blk2 = (int32_t*)take((N + 4) + (T / 64 + N + 1) * 4);
   w.bytes = o;
   return w;
 }
@@ -473,12 +618,43 @@ struct Ctx {
   hipStream_t s;
   TrainWs ws;
   int T, N;
+  bool eval = false;      // predictor.model.eval() (trainer.py:171): no dropout, forward only
+  int n_gemm = 0;         // split GEMMs so far in this step (index into ws.scales)
 };
 
-int gemm_nt(const float* A, const float* B, const float* bias, const float* resid, float* out, int M, int N, int K, int relu,
-            hipStream_t s) {
+// C[M, N] = A[M, K] B[N, K]^T (+ bias)(ReLU)(+ resid), all f32 in memory
+int gemm_nt(Ctx& c, const float* A, const float* B, const float* bias, const float* resid, float* out, int M, int N, int K,
+            int relu, AOp* planes = nullptr /*fp16 path: also write the result as row-major hi | lo planes; cleared if it did not*/) {
+  hipStream_t s = c.s;
   GemmArgs g{};
-  g.a = AOp{(void*)A, nullptr}; g.w = B; g.bias = bias; g.resid = resid; g.out_f32 = out; g.M = M; g.N = N; g.K = K; g.relu = relu;
+  g.bias = bias; g.resid = resid; g.out_f32 = out; g.M = M; g.N = N; g.relu = relu;
+  if (!c.t->use_f32 && K % 32 == 0 && N % 64 == 0) {
+    // split both operands: [A | A] [Bh | Bl]^T over K' = 2K on the split-fp16 kernel (Ah Bh + Al Bh + Ah Bl + Al Bl),
+    // each operand scaled into fp16's range by a power of two first (split_scale), undone by gemm_finish_kernel
+    if (c.n_gemm >= MAX_GEMMS) { set_error("ltr_train_step: more than %d GEMMs in one step", MAX_GEMMS); return LTR_E_INVAL; }
+    float* sl = c.ws.scales + 2 * (c.n_gemm++);
+    amax_kernel<<<(unsigned)std::min<size_t>(((size_t)M * K + 4095) / 4096, 2048), 256, 0, s>>>(A, (size_t)M * K, sl);
+    amax_kernel<<<(unsigned)std::min<size_t>(((size_t)N * K + 4095) / 4096, 2048), 256, 0, s>>>(B, (size_t)N * K, sl + 1);
+    __half* ah = reinterpret_cast<__half*>(c.ws.opa);
+    __half* al = ah + (size_t)M * 2 * K;
+    const size_t apieces = (size_t)M * K / 8;
+    split_operand_dup_kernel<<<(unsigned)((apieces + 255) / 256), 256, 0, s>>>(A, ah, al, M, K, sl);
+    const size_t pieces = (size_t)N * K / 4;
+    split_pack_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>(B, reinterpret_cast<__half*>(c.ws.wb), N, K, sl + 1);
+    LTR_LAUNCH_CHECK();
+    GemmArgs r{};
+    r.a = AOp{ah, al}; r.w = c.ws.wb; r.out_f32 = c.ws.gtmp; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
+    int rc = launch_gemm(LTR_W_F16, r, s);
+    if (rc) return rc;
+    const size_t n8 = (size_t)M * N / 8;
+    gemm_finish_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, sl, bias, resid, out, n8, N, relu,
+                                                                   planes ? (__half*)planes->hi : nullptr,
+                                                                   planes ? (__half*)planes->lo : nullptr);
+    LTR_LAUNCH_CHECK();
+    return LTR_OK;
+  }
+  if (planes) *planes = AOp{nullptr, nullptr};
+  g.a = AOp{(void*)A, nullptr}; g.w = B; g.K = K;
   return launch_gemm(LTR_W_F32, g, s);
 }
 int transpose_pad(const float* in, int R, int C, int Rp, float* out, hipStream_t s) {
@@ -491,22 +667,22 @@ int transpose_pad(const float* in, int R, int C, int Rp, float* out, hipStream_t
 int gemm_nn(Ctx& c, const float* dY, const float* W, const float* resid, float* dX, int M, int N, int K) {
   int rc = transpose_pad(W, N, K, N, c.t->wT, c.s);          // W^T [K, N]
   if (rc) return rc;
-  return gemm_nt(dY, c.t->wT, nullptr, resid, dX, M, K, N, 0, c.s);
+  return gemm_nt(c, dY, c.t->wT, nullptr, resid, dX, M, K, N, 0);
 }
 // dW[N, K] = dY[M, N]^T X[M, K]
 int gemm_tn(Ctx& c, const float* dY, const float* X, float* dW, int M, int N, int K) {
-  const int Mp = (M + 15) / 16 * 16;
+  const int Mp = (M + 31) / 32 * 32;
   int rc = transpose_pad(dY, M, N, Mp, c.ws.t1, c.s);        // [N, Mp]
   if (rc) return rc;
   if ((rc = transpose_pad(X, M, K, Mp, c.ws.t2, c.s))) return rc;   // [K, Mp]
-  return gemm_nt(c.ws.t1, c.ws.t2, nullptr, nullptr, dW, N, K, Mp, 0, c.s);
+  return gemm_nt(c, c.ws.t1, c.ws.t2, nullptr, nullptr, dW, N, K, Mp, 0);
 }
 int colsum(Ctx& c, const float* x, const float* y, int M, int N, float* out) {
-  const int nb = (M + 255) / 256;
+  const int nb = (M + CS_ROWS - 1) / CS_ROWS;
   dim3 grid((N + 255) / 256, nb);
   colsum_partial_kernel<<<grid, 256, 0, c.s>>>(x, y, M, N, c.ws.partial);
   LTR_LAUNCH_CHECK();
-  colsum_final_kernel<<<(N + 255) / 256, 256, 0, c.s>>>(c.ws.partial, nb, N, out);
+  colsum_final_kernel<<<(N + 63) / 64, 256, 0, c.s>>>(c.ws.partial, nb, N, out);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
@@ -529,12 +705,12 @@ int forward(Ctx& c, const int64_t* ids, const int32_t* cu) {
   ltr_trainer* t = c.t;
   const ltr_model_desc& d = t->d;
   const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, T = c.T, N = c.N, nl = d.num_labels;
-  const bool proj = De != H, drop = t->cfg.dropout > 0.f;
+  const bool proj = De != H, drop = t->cfg.dropout > 0.f && !c.eval;
   hipStream_t s = c.s;
   float* h0 = d.num_layers ? c.ws.L[0].x0 : c.ws.hfin;
   RC(launch_embed_gather(LTR_W_F32, ids, cu, N, T, 0, t->p(LTR_WT_EMBED_TOKENS), De, d.vocab_size, t->p(LTR_WT_EMBED_POS), H,
                          d.pos_rows, h0, AOp{c.ws.tok, nullptr}, nullptr, s));
-  if (proj) RC(gemm_nt(c.ws.tok, t->p(LTR_WT_PROJECT_IN), nullptr, h0, h0, T, H, De, 0, s));
+  if (proj) RC(gemm_nt(c, c.ws.tok, t->p(LTR_WT_PROJECT_IN), nullptr, h0, h0, T, H, De, 0));
   for (int l = 0; l < d.num_layers; ++l) {
     auto& L = c.ws.L[l];
     float* out = l + 1 < d.num_layers ? c.ws.L[l + 1].x0 : c.ws.hfin;
@@ -543,16 +719,31 @@ int forward(Ctx& c, const int64_t* ids, const int32_t* cu) {
       RC(launch_layernorm(LTR_W_F32, L.x0, t->p(t->li(l, LTR_WL_LN1_W)), t->p(t->li(l, LTR_WL_LN1_B)), T, H, L.n1, AOp{nullptr, nullptr}, s));
       qkv_in = L.n1;
     }
-    RC(gemm_nt(qkv_in, t->p(t->li(l, LTR_WL_QKV_W)), t->p(t->li(l, LTR_WL_QKV_B)), nullptr, L.qkv, T, 3 * H, H, 0, s));
-    RC(launch_attention(LTR_W_F32, AOp{L.qkv, nullptr}, cu, N, T, H, d.num_heads, c.ws.blk, AOp{L.ao, nullptr}, l == 0, s, L.lse));
+    // QKV: f32 for the backward and - on the fp16 path - hi | lo planes for the MFMA attention kernel of the scoring
+    // path (three split passes, f32 softmax; it also hands out the log-sum-exp rows the backward recomputes P from)
+    __half* qp = reinterpret_cast<__half*>(c.ws.qkvp);
+    AOp planes{qp, qp + (size_t)T * 3 * H};
+    RC(gemm_nt(c, qkv_in, t->p(t->li(l, LTR_WL_QKV_W)), t->p(t->li(l, LTR_WL_QKV_B)), nullptr, L.qkv, T, 3 * H, H, 0, &planes));
+    static const bool f32_attn = [] { const char* e = getenv("LTR_TRAIN_F32_ATTN"); return e && e[0] == '1'; }();   // A/B
+    if (planes.hi && !f32_attn) {
+      __half* op = reinterpret_cast<__half*>(c.ws.aop);
+      // (own work list: the MFMA kernel walks 128-query blocks, the backward kernels 64-query blocks from ws.blk)
+      if (l == 0) RC(launch_attention_blocks(cu, N, 64, c.ws.blk, s));
+      RC(launch_attention(LTR_W_F16, planes, cu, N, T, H, d.num_heads, c.ws.blk2, AOp{op, op + (size_t)T * H}, l == 0, s, L.lse));
+      const size_t n8 = (size_t)T * H / 8;
+      planes_to_f32_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(op, op + (size_t)T * H, L.ao, n8);
+      LTR_LAUNCH_CHECK();
+    } else {
+      RC(launch_attention(LTR_W_F32, AOp{L.qkv, nullptr}, cu, N, T, H, d.num_heads, c.ws.blk, AOp{L.ao, nullptr}, l == 0, s, L.lse));
+    }
     // s1 = x0 + dropout(out_proj(ao))
     float* s1 = d.pre_ln ? L.mid : L.n1;
     if (drop) {
-      RC(gemm_nt(L.ao, t->p(t->li(l, LTR_WL_OUT_W)), t->p(t->li(l, LTR_WL_OUT_B)), nullptr, L.ao_raw, T, H, H, 0, s));
+      RC(gemm_nt(c, L.ao, t->p(t->li(l, LTR_WL_OUT_W)), t->p(t->li(l, LTR_WL_OUT_B)), nullptr, L.ao_raw, T, H, H, 0));
       dropout_add_kernel<<<1024, 256, 0, s>>>(L.ao_raw, L.x0, s1, (size_t)T * H, drop_seed(t, l, 0), t->cfg.dropout);
       LTR_LAUNCH_CHECK();
     } else {
-      RC(gemm_nt(L.ao, t->p(t->li(l, LTR_WL_OUT_W)), t->p(t->li(l, LTR_WL_OUT_B)), L.x0, s1, T, H, H, 0, s));
+      RC(gemm_nt(c, L.ao, t->p(t->li(l, LTR_WL_OUT_W)), t->p(t->li(l, LTR_WL_OUT_B)), L.x0, s1, T, H, H, 0));
     }
     const float* mlp_in;
     if (d.pre_ln) {
@@ -562,14 +753,14 @@ int forward(Ctx& c, const int64_t* ids, const int32_t* cu) {
       RC(launch_layernorm(LTR_W_F32, L.n1, t->p(t->li(l, LTR_WL_LN1_W)), t->p(t->li(l, LTR_WL_LN1_B)), T, H, L.mid, AOp{nullptr, nullptr}, s));
       mlp_in = L.mid;
     }
-    RC(gemm_nt(mlp_in, t->p(t->li(l, LTR_WL_FC1_W)), t->p(t->li(l, LTR_WL_FC1_B)), nullptr, L.f, T, F, H, 1, s));
+    RC(gemm_nt(c, mlp_in, t->p(t->li(l, LTR_WL_FC1_W)), t->p(t->li(l, LTR_WL_FC1_B)), nullptr, L.f, T, F, H, 1));
     float* s2 = d.pre_ln ? out : L.n2;
     if (drop) {
-      RC(gemm_nt(L.f, t->p(t->li(l, LTR_WL_FC2_W)), t->p(t->li(l, LTR_WL_FC2_B)), nullptr, L.mlp_raw, T, H, F, 0, s));
+      RC(gemm_nt(c, L.f, t->p(t->li(l, LTR_WL_FC2_W)), t->p(t->li(l, LTR_WL_FC2_B)), nullptr, L.mlp_raw, T, H, F, 0));
       dropout_add_kernel<<<1024, 256, 0, s>>>(L.mlp_raw, L.mid, s2, (size_t)T * H, drop_seed(t, l, 1), t->cfg.dropout);
       LTR_LAUNCH_CHECK();
     } else {
-      RC(gemm_nt(L.f, t->p(t->li(l, LTR_WL_FC2_W)), t->p(t->li(l, LTR_WL_FC2_B)), L.mid, s2, T, H, F, 0, s));
+      RC(gemm_nt(c, L.f, t->p(t->li(l, LTR_WL_FC2_W)), t->p(t->li(l, LTR_WL_FC2_B)), L.mid, s2, T, H, F, 0));
     }
     if (!d.pre_ln)
       RC(launch_layernorm(LTR_W_F32, L.n2, t->p(t->li(l, LTR_WL_LN2_W)), t->p(t->li(l, LTR_WL_LN2_B)), T, H, out, AOp{nullptr, nullptr}, s));
@@ -585,7 +776,7 @@ int forward(Ctx& c, const int64_t* ids, const int32_t* cu) {
     z = c.ws.z;
   }
   const float* y = z;
-  if (proj) { RC(gemm_nt(z, t->p(LTR_WT_PROJECT_OUT), nullptr, nullptr, c.ws.y, N, De, H, 0, s)); y = c.ws.y; }
+  if (proj) { RC(gemm_nt(c, z, t->p(LTR_WT_PROJECT_OUT), nullptr, nullptr, c.ws.y, N, De, H, 0)); y = c.ws.y; }
   head_fwd_kernel<<<(unsigned)(((size_t)N * nl + 3) / 4), 256, 0, s>>>(y, t->p(LTR_WT_SCORE), N, De, nl, c.ws.logits);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
@@ -729,6 +920,7 @@ int ltr_train_create(const ltr_model_desc* desc, const void* const* weights, int
   ltr_trainer* t = new (std::nothrow) ltr_trainer();
   if (!t) { set_error("ltr_train_create: out of host memory"); return LTR_E_NOMEM; }
   t->d = d; t->cfg = *cfg;
+  { const char* e = getenv("LTR_TRAIN_F32"); t->use_f32 = e && e[0] == '1'; }
   t->off.resize(want); t->cnt.resize(want);
   size_t total = 0, wmax = 0;
   for (int i = 0; i < want; ++i) {
@@ -795,7 +987,7 @@ int ltr_train_read(ltr_train_handle h, int32_t index, int32_t what, float* dst, 
 int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* cu_seqlens, const int32_t* cu_seqlens_host,
                    int32_t N, int32_t T, const float* labels, const int32_t* shuffle, int32_t apply_update, float* loss_out,
                    float* logits_out, void* workspace, size_t ws_bytes, void* stream) {
-  if (!h || !token_ids || !cu_seqlens || !cu_seqlens_host || !labels || !loss_out || !workspace || N <= 0 || T <= 0) {
+  if (!h || !token_ids || !cu_seqlens || !cu_seqlens_host || (apply_update >= 0 && (!labels || !loss_out)) || !workspace || N <= 0 || T <= 0) {
     set_error("ltr_train_step: bad argument"); return LTR_E_INVAL;
   }
   const ltr_model_desc& d = h->d;
@@ -804,15 +996,18 @@ int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* 
     const int L = cu_seqlens_host[r + 1] - cu_seqlens_host[r];
     if (L <= 0 || L > d.pos_rows - 2) { set_error("ltr_train_step: request %d has %d tokens (1..%d allowed)", r, L, d.pos_rows - 2); return LTR_E_INVAL; }
   }
-  if (h->cfg.loss == LTR_LOSS_LISTMLE && (!shuffle || N > 4096)) { set_error("ltr_train_step: listMLE needs the shuffle permutation and a slate of at most 4096"); return LTR_E_INVAL; }
+  if (apply_update >= 0 && h->cfg.loss == LTR_LOSS_LISTMLE && (!shuffle || N > 4096)) { set_error("ltr_train_step: listMLE needs the shuffle permutation and a slate of at most 4096"); return LTR_E_INVAL; }
   DevGuard guard(h->device);
   hipStream_t s = (hipStream_t)stream;
   Ctx c{h, s, carve_train(d, T, N, workspace, h->cfg.dropout > 0.f), T, N};
+  c.eval = apply_update < 0;
+  if (!h->use_f32 && c.ws.bytes <= ws_bytes) LTR_HIP_CHECK(hipMemsetAsync(c.ws.scales, 0, MAX_GEMMS * 2 * sizeof(float), s));
   if (c.ws.bytes > ws_bytes) { set_error("ltr_train_step: workspace too small (%zu < %zu)", ws_bytes, c.ws.bytes); return LTR_E_NOMEM; }
   int rc = forward(c, token_ids, cu_seqlens);
   if (rc) return rc;
   const int nl = d.num_labels;
   if (logits_out) LTR_HIP_CHECK(hipMemcpyAsync(logits_out, c.ws.logits, (size_t)N * nl * 4, hipMemcpyDeviceToDevice, s));
+  if (c.eval) return LTR_OK;                    // evaluation pass (trainer.py:171-190): the outputs are all that is wanted
   if (h->cfg.loss == LTR_LOSS_LISTMLE) {       // trainer.py:157: loss_func(outputs.view(1, -1), labels) - the batch is one slate
     rc = ltr_listmle(c.ws.logits, labels, shuffle, 1, N, h->cfg.listmle_eps, h->cfg.pad_value, loss_out, c.ws.row_loss,
                      c.ws.dlogits, stream);

@@ -36,13 +36,23 @@ def len2label(length: int, label_max_length: int = 8192, label_group_size: int =
 class HipPredictorTrainer:
     def __init__(self, spec: OPTSpec, ckpt: Dict[str, np.ndarray], device: str = "cuda:0", lr: float = 2e-5,
                  weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, loss: str = "listMLE",
-                 dropout: float = 0.0, seed: int = 42):
+                 dropout: float = 0.0, seed: int = 42, precision: str = "split"):
         """Defaults are the reference's: ``--lr 2e-5 --wc 0.01`` (trainer.py:28-29), Adam's betas / eps, seed 42 (:86).
-        ``dropout``: HF OPT trains with 0.1; 0 keeps the step reproducible against other implementations."""
+        ``dropout``: HF OPT trains with 0.1; 0 keeps the step reproducible against other implementations.
+        ``precision``: how the dense layers multiply - "split" (default): both operands as two fp16 terms on the fp16
+        matrix cores (f32-grade products, f32 accumulation; the reference itself trains under fp16 autocast,
+        trainer.py:147) and the scoring path's MFMA attention in the forward; "f32": the exact-f32 MFMA everywhere."""
+        if precision not in ("split", "f32"):
+            raise ValueError(f"precision {precision!r}: 'split' or 'f32'")
+        self.precision = precision
         if not torch.cuda.is_available():
             raise _lib.LtrError("HipPredictorTrainer needs a ROCm GPU (no CPU fallback on the product path)")
+        if loss == "neuralNDCG":
+            raise NotImplementedError("loss 'neuralNDCG' (trainer.py:127-128, allrank/models/losses/neuralNDCG.py) is not built: "
+                                      "every recipe in train/train.sh uses listMLE or the class heads; use listMLE, mse or "
+                                      "crossentropy")
         if loss not in _lib.LOSSES:
-            raise ValueError(f"loss {loss!r}: one of {sorted(_lib.LOSSES)} (trainer.py:125-132; neuralNDCG is not built)")
+            raise ValueError(f"loss {loss!r}: one of {sorted(_lib.LOSSES)} (trainer.py:125-132)")
         self.lib = _lib.load()
         self.spec, self.loss = spec, loss
         self.device = torch.device(device)
@@ -72,9 +82,17 @@ class HipPredictorTrainer:
                               1 if spec.do_layer_norm_before else 0, _lib.LTR_W_F32)
         cfg = _lib.TrainConfig(lr, betas[0], betas[1], eps, weight_decay, _lib.LOSSES[loss], 1e-10, -1.0, dropout, seed)
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.ltr_train_create(C.byref(desc), ptrs, len(g), C.byref(cfg), self._stream(), C.byref(self._h)),
-                       "ltr_train_create")
+        prev = os.environ.get("LTR_TRAIN_F32")
+        os.environ["LTR_TRAIN_F32"] = "1" if precision == "f32" else "0"        # read by ltr_train_create
+        try:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.ltr_train_create(C.byref(desc), ptrs, len(g), C.byref(cfg), self._stream(), C.byref(self._h)),
+                           "ltr_train_create")
+        finally:
+            if prev is None:
+                del os.environ["LTR_TRAIN_F32"]
+            else:
+                os.environ["LTR_TRAIN_F32"] = prev
         del g                                    # the library copied the weights
         self._n_weights = len(ptrs)
         self._ws: Optional[torch.Tensor] = None
@@ -135,6 +153,60 @@ class HipPredictorTrainer:
         self.steps += 1
         out = float(loss.item())
         return (out, logits.cpu().numpy()) if return_logits else out
+
+    def predict(self, ids: np.ndarray, cu_seqlens: np.ndarray) -> np.ndarray:
+        """``predictor.model.eval()`` forward with the current f32 weights (trainer.py:171-190): logits [N, num_labels]."""
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        N, T = cu.shape[0] - 1, int(cu[-1])
+        dev = self.device
+        ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(dev)
+        cu_d = torch.from_numpy(cu).to(dev)
+        need = int(self.lib.ltr_train_workspace_bytes(self._h, N, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        logits = torch.empty(N, self.spec.num_labels, dtype=torch.float32, device=dev)
+        _lib.check(self.lib.ltr_train_step(self._h, ids_d.data_ptr(), cu_d.data_ptr(), cu.ctypes.data, N, T, None, None, -1,
+                                           None, logits.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self._stream()),
+                   "ltr_train_step(eval)")
+        return logits.cpu().numpy()
+
+    def fit(self, train: Sequence, test: Sequence, epochs: int = 1, batch_size: int = 32, seed: int = 42,
+            log=print) -> List[dict]:
+        """The loop of train/trainer.py:134-200.  ``train`` / ``test``: sequences of ``(token_ids, label)`` with
+        ``label = len2label(output_length, ...)`` (RankingDataset, :50-66).  Per epoch: the examples in a fresh random
+        order (``DataLoader(shuffle=True)``, :118) in slates of ``batch_size`` -> :meth:`step`; then the evaluation pass
+        (:167-200): predictions of the test examples, Kendall's tau against their labels (``scipy.stats.kendalltau``,
+        :195) and, for crossentropy, the accuracy (:198-199).  Returns one record per epoch."""
+        from scipy.stats import kendalltau
+        from .scorer import HipOPTScorer
+        rs = np.random.RandomState(seed)
+        hist = []
+        for epoch in range(epochs):
+            order = rs.permutation(len(train))
+            total, nb = 0.0, 0
+            for b0 in range(0, len(order), batch_size):
+                idx = order[b0:b0 + batch_size]
+                ids, cu = HipOPTScorer.pack([train[i][0] for i in idx])
+                total += self.step(ids, cu, np.asarray([train[i][1] for i in idx], np.float32),
+                                   shuffle=rs.permutation(len(idx)) if self.loss == "listMLE" else None)
+                nb += 1
+            preds, truth = [], []
+            for b0 in range(0, len(test), batch_size):
+                chunk = test[b0:b0 + batch_size]
+                ids, cu = HipOPTScorer.pack([t[0] for t in chunk])
+                out = self.predict(ids, cu)
+                preds.extend(out.argmax(-1).tolist() if self.loss == "crossentropy" else out[:, 0].tolist())   # :186-189
+                truth.extend(t[1] for t in chunk)
+            tau, pval = kendalltau(truth, preds) if len(truth) > 1 else (float("nan"), float("nan"))
+            rec = dict(epoch=epoch + 1, loss=total / max(nb, 1), kendall_tau=float(tau), p_value=float(pval))
+            if self.loss == "crossentropy":
+                rec["acc"] = float((np.asarray(truth) == np.asarray(preds)).mean())
+            if log:
+                log(f"Epoch {epoch + 1}, Loss: {rec['loss']}")                               # :165
+                log(f"Kendall's Tau: {rec['kendall_tau']}, p-value: {rec['p_value']}")        # :196
+            hist.append(rec)
+        return hist
 
     def step_lists(self, token_lists: Sequence[Sequence[int]], labels, **kw):
         from .scorer import HipOPTScorer
