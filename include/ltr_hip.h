@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LTR_ABI_VERSION 2
+#define LTR_ABI_VERSION 3
 
 enum {
   LTR_OK = 0,

@@ -75,8 +75,35 @@ def forward(orc: OracleOPTScorer, ids, cu, use, mx):
     return orc.pool_head(h, torch.as_tensor(cu[1:].astype(np.int64) - 1))[:, 0].numpy()
 
 
+def tail_study(n_req: int):
+    """Round 3: the 3.4e-5 / 6.0e-5 above are maxima over the 12 golden requests; the bar is 1e-4 on EVERY request of an
+    8k queue.  Distribution of the error over the first n_req requests of the bench queue (OPT-125m, seed 0)."""
+    from vllm_ltr_amd.opt_spec import OPTSpec
+    sys.path.insert(0, ROOT)
+    import bench
+    spec = OPTSpec.opt_125m()
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = bench.synthetic_queue(spec, 8192, 0)
+    ids, cu = ids[:cu[n_req]], cu[:n_req + 1].astype(np.int64)
+    orc = OracleOPTScorer(spec, ckpt)
+    out = {}
+    with torch.no_grad():
+        for label, use in (("fp16 lo (production)", ()), ("fp8 lo in fc1 + fc2", ("fc1", "fc2")),
+                           ("fp8 lo in all four", ("qkv", "out", "fc1", "fc2"))):
+            got = np.concatenate([forward(orc, ids[cu[i]:cu[j]], cu[i:j + 1] - cu[i], use, True)
+                                  for i, j in zip(range(0, n_req, 16), list(range(16, n_req, 16)) + [n_req])])
+            out[label] = got
+    ref = out["fp16 lo (production)"]
+    for label, got in out.items():
+        e = np.abs(got - ref)
+        print(f"tail over {n_req} requests, {label:24s} vs the production arithmetic: max {e.max():.2e}  p99 {np.percentile(e, 99):.2e}  "
+              f"p50 {np.percentile(e, 50):.2e}  rms {np.sqrt((e ** 2).mean()):.2e}")
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if len(sys.argv) > 2 and sys.argv[1] == "--tail":
+        return tail_study(int(sys.argv[2]))
     for name in ("opt125m", "opt350m"):
         z = np.load(os.path.join(ROOT, "tests", "golden", f"score_{name}.npz"))
         spec = spec_from_npz(z)

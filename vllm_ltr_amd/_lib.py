@@ -25,7 +25,7 @@ SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "lt
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
            "ltr_train_step", "ltr_train_read", "ltr_attention")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LtrError(RuntimeError):
