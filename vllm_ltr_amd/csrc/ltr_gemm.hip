@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
   }
   float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;      // LNP: gamma * scale; LNC: c_n
-  if (LNM != LN_NONE && ccol < N) {
+  if (LNM != LN_NONE && !RLN && ccol < N) {                            // (RLN instances fetch it in their second sweep)
     const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
     lnv_a = *reinterpret_cast<const float4*>(src + ccol);
     lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
@@ -471,23 +471,68 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (ccol < N && RLN) {
-      // LayerNorm'd residual: ONE row at a time.  The two-row prefetch of the branch below plus the affine vectors of the
-      // residual's LayerNorm do not fit the 128-VGPR budget of four waves per SIMD: the compiler spilled (also with bias /
-      // gamma fetched at their point of use instead of held in registers: 36 B per lane left), and the spilled LNP + RLN
-      // instance produced NaNs - its inline-asm stores sit behind scratch reloads.
+      // LayerNorm'd residual in TWO sweeps over the strip.  Everything at once - two rows of accumulator + residual in
+      // flight, the affine vectors of the residual's LayerNorm, bias, the producer's gamma - does not fit the 128-VGPR
+      // budget of four waves per SIMD: the compiler spilled, and the spilled LNP + RLN instance produced NaNs (its
+      // inline-asm stores sit behind scratch reloads).  Sweep 1 turns the strip into x = acc + bias + LN(resid) in
+      // place (wave-local LDS), sweep 2 is the ordinary epilogue on x.  (One row at a time in one sweep also fits, and
+      // cost OPT-350m's producers 8 %.)
+      float4 ra[2], rb[2];
+      int gr[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {            // both rows' residuals in flight (global), the accumulators come from LDS
+        gr[it] = m0 + wr * 64 + st * 16 + it * 8 + erow;
+        ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[it] = ra[it];
+        if (gr[it] < M) {
+          const size_t o = (size_t)gr[it] * N + ccol;
+          ra[it] = *reinterpret_cast<const float4*>(ep.resid + o);
+          rb[it] = *reinterpret_cast<const float4*>(ep.resid + o + (ecol_b - ecol));
+        }
+      }
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int srow = it * 8 + erow;
-        const int grow = m0 + wr * 64 + st * 16 + srow;
-        if (grow >= M) continue;
-        const size_t o = (size_t)grow * N + ccol;
-        const float4 va = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
-        const float4 vb = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
-        const float4 ra = *reinterpret_cast<const float4*>(ep.resid + o);
-        const float4 rb = *reinterpret_cast<const float4*>(ep.resid + o + (ecol_b - ecol));
-        const float2 st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[grow - m0];
-        epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
-                                 tn * 4 + wc);
+        const float2 rst = reinterpret_cast<const float2*>(smem + 2 * STAGE)[min(gr[it], M - 1) - m0];
+        {
+          const float4 va = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
+          const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol);
+          float4 x;
+          x.x = va.x + bias_a.x + ((ra[it].x - rst.x) * rst.y * g.x + b.x);
+          x.y = va.y + bias_a.y + ((ra[it].y - rst.x) * rst.y * g.y + b.y);
+          x.z = va.z + bias_a.z + ((ra[it].z - rst.x) * rst.y * g.z + b.z);
+          x.w = va.w + bias_a.w + ((ra[it].w - rst.x) * rst.y * g.w + b.w);
+          *reinterpret_cast<float4*>(s_c + srow * CLD + ecol) = x;
+        }
+        {
+          const float4 vb = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
+          const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol_b), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol_b);
+          float4 x;
+          x.x = vb.x + bias_b.x + ((rb[it].x - rst.x) * rst.y * g.x + b.x);
+          x.y = vb.y + bias_b.y + ((rb[it].y - rst.x) * rst.y * g.y + b.y);
+          x.z = vb.z + bias_b.z + ((rb[it].z - rst.x) * rst.y * g.z + b.z);
+          x.w = vb.w + bias_b.w + ((rb[it].w - rst.x) * rst.y * g.w + b.w);
+          *reinterpret_cast<float4*>(s_c + srow * CLD + ecol_b) = x;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 ga = z4, gb = z4;                     // the producer's gamma * scale, fetched here (not held across sweep 1)
+      if (LNM == LNP) {
+        ga = *reinterpret_cast<const float4*>(ep.ln_gamma + ccol);
+        gb = *reinterpret_cast<const float4*>(ep.ln_gamma + ccol_b);
+        ga.x *= LN_FOLD_SCALE; ga.y *= LN_FOLD_SCALE; ga.z *= LN_FOLD_SCALE; ga.w *= LN_FOLD_SCALE;
+        gb.x *= LN_FOLD_SCALE; gb.y *= LN_FOLD_SCALE; gb.z *= LN_FOLD_SCALE; gb.w *= LN_FOLD_SCALE;
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        if (gr[it] >= M) continue;
+        const int srow = it * 8 + erow;
+        const float4 xa = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
+        const float4 xb = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
+        epilogue_piece<LNM, false>(ep, xa, xb, z4, z4, z4, z4, ga, gb, make_float2(0.f, 0.f), make_float2(0.f, 0.f), gr[it],
+                                   ccol, ccol_b, (size_t)gr[it] * N + ccol, M, lane, tn * 4 + wc);
       }
     } else     if (ccol < N) {
       float4 va[2], vb[2], ra[2], rb[2];
@@ -896,7 +941,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
               g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : LN_NONE);
   const bool rln = g.rln_stats != nullptr;
-  if (rln && (wdtype != LTR_W_F16 || lnm == LNC || !g.resid || !g.rln_gamma || !g.rln_beta || g.rln_parts * 64 != g.N ||
+  if (rln && (wdtype != LTR_W_F16 || lnm == LNC || g.relu || !g.resid || !g.rln_gamma || !g.rln_beta || g.rln_parts * 64 != g.N ||
               g.rln_stats == g.ln_stats_out)) {
     set_error("gemm: a LayerNorm'd residual needs F16 mode, resid, gamma / beta [N], N / 64 statistics pieces distinct from the "
               "producer's output and no consumer epilogue");
