@@ -1,5 +1,3 @@
-O=gpurun_out/r03_m; mkdir -p $O
-python -m pytest tests/test_gpu_scorer.py tests/test_gpu_small_batches.py tests/test_gpu_gemm_epilogue.py tests/test_gpu_full_configs.py -m gpu -q > $O/t1.log 2>&1; tail -4 $O/t1.log
-for i in 1 2; do python bench.py --model 350m --profile lmsys --no-cpu-baseline --no-strong --no-unfused --no-class-head --steady-new 0 --steps 3 --warmup 1 2>> $O/bench.err | tee $O/bench350.json | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],1), {k:(round(v.get('ms_per_step') or 0,2), v.get('launches_per_step')) for k,v in d['kernels'].items()})"; done
+O=gpurun_out/r03_n; mkdir -p $O
+LTR_GEMM_DEEP_TILES=600 LTR_GEMM_DEEP_M=1024 python -m pytest tests/test_gpu_small_batches.py tests/test_gpu_gemm_epilogue.py -m gpu -q -k "not latency" > $O/t1.log 2>&1; tail -3 $O/t1.log
+for cfg in "0 0" "1024 320" "1024 600" "1024 1200" "3072 600" "3072 1200" "512 600"; do set -- $cfg; echo "DEEP_M=$1 DEEP_TILES=$2"; LTR_GEMM_DEEP_M=$1 LTR_GEMM_DEEP_TILES=$2 python tests/diag/small_call_profile.py 4 8 16 32 64 128 256 2>/dev/null | cut -c1-100; done | tee $O/ab_deep.txt

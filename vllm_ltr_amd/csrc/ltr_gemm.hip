@@ -594,20 +594,29 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 //    epilogue arithmetic as the large-tile kernel: results are BIT-IDENTICAL to it, so a request's score does not
 //    depend on which kernel a batch size selects (tests/test_gpu_small_batches.py).
 // ------------------------------------------------------------------------------------
-constexpr int SKS = 64;          // K per stage = two 32-wide slabs
-template <int BM_, int BN_, int SSTAGES> struct SmallCfg {
-  static constexpr int WM = 2, WN = BN_ / 32;                       // 32 x 64 -> 2 x 2 waves (16 x 32 each); 64 x 128 -> 2 x 4 (32 x 32)
+// Configuration of gemm_f16s_small_kernel: BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN)), SL 32-wide K-slabs
+// per ring stage, SSTAGES stages.  The shipped instances:
+//   32 x  64, 2 x 2 waves, 64-wide stages, ring of 4 (64 KiB)   - up to 1,024 rows (a handful of arrivals)
+//   64 x 128, 2 x 4 waves, 64-wide stages, ring of 4 (128 KiB)  - up to 3,072 rows
+// (128 x 256, 2 x 4 waves, 32-wide stages, ring of 4 - the large-tile kernel's tile behind a deep ring at one workgroup
+//  per CU - also instantiates and is parity-green, but loses to its neighbours at every size: see launch_gemm)
+template <int BM_, int BN_, int WM_, int WN_, int SL_, int SSTAGES> struct SmallCfg {
+  static constexpr int WM = WM_, WN = WN_;
   static constexpr int NW = WM * WN;
   static constexpr int TI = BM_ / WM / 16, TJ = BN_ / WN / 16;      // MFMA blocks per wave
   static constexpr int PA = BM_ / 16 * 2, PW = BN_ / 16;            // 1-KiB DMA pieces per 32-wide slab: A hi|lo, W
   static constexpr int SUB = (PA + PW) * 512;                       // halves per 32-wide slab image
-  static constexpr int STAGE_H = 2 * SUB;                           // halves per stage
-  static constexpr int PIECES = 2 * (PA + PW) / NW;                 // DMA instructions per wave and stage
+  static constexpr int SL = SL_;                                    // slabs per stage
+  static constexpr int STAGE_H = SL * SUB;                          // halves per stage
+  static constexpr int PIECES = SL * (PA + PW) / NW;                // DMA instructions per wave and stage
   static constexpr int CLDS = BN_ + 4;                              // f32 row stride of the epilogue tile
+  static constexpr int EH = ((size_t)BM_ * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2) ? 1 : WM;   // epilogue passes (row blocks of the waves)
+  static constexpr int EROWS = BM_ / EH;
   static constexpr size_t LDS_BYTES = (size_t)SSTAGES * STAGE_H * 2 + BM_ * 8;
-  static_assert(2 * (PA + PW) % NW == 0 && PIECES == 4, "piece map assumes 4 DMA instructions per wave and stage");
+  static_assert(SL * (PA + PW) % NW == 0 && PIECES >= 1 && PIECES <= 4, "piece map: 1-4 DMA instructions per wave and stage");
   static_assert(SSTAGES >= 3 && SSTAGES <= 8, "counted vmcnt waits cover up to 6 stages in flight");
-  static_assert((size_t)BM_ * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2, "epilogue tile must fit the ring");
+  static_assert((size_t)EROWS * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2, "epilogue tile must fit the ring");
+  static_assert(BM_ % (WM * 16) == 0 && BN_ % (WN * 16) == 0 && (EROWS * BN_ / 8) % (NW * 64) == 0, "tile / wave grid mismatch");
 };
 
 // Workgroup -> tile map of the small-tile kernels: the 8 XCDs (block b runs on XCD b % 8, private 4 MiB L2s) form an
@@ -633,11 +642,11 @@ __device__ __forceinline__ bool xcd_tile(int bid, int tiles_m, int tiles_n, XcdM
   return true;
 }
 
-template <int LNM, bool RLN, int BM_, int BN_, int SSTAGES>
-__global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f16s_small_kernel(
+template <int LNM, bool RLN, int BM_, int BN_, int WM_, int WN_, int SL_, int SSTAGES>
+__global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::NW * 64)) gemm_f16s_small_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int tiles_m, int tiles_n, XcdMap xmap, Epilogue ep) {
-  using C = SmallCfg<BM_, BN_, SSTAGES>;
+  using C = SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>;
   // dynamic LDS on purpose: with a static array hipcc tracks the LDS-DMA stores against every ds_read and drains
   // vmcnt(0) in front of the first fragment read of each stage (ltr_attn.hip has the same note)
   extern __shared__ __attribute__((aligned(16))) __half smem[];
@@ -649,14 +658,15 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / C::WN, wc = wave % C::WN;
 
-  // this wave's four DMA pieces of a stage: piece q = wave * 4 + p of the stage's 2 x (PA + PW); slab q / (PA + PW),
+  // this wave's DMA pieces of a stage: piece q = wave * PIECES + p of the stage's SL x (PA + PW); slab q / (PA + PW),
   // then r = q % (PA + PW): A hi groups, A lo groups, W groups - the LDS image of a slab is exactly r * 1 KiB
-  const __half* gsrc[4];
-  size_t gstep[4];      // source advance per 32-wide slab
-  int ldst[4];          // halves from the stage base
+  constexpr int NP = C::PIECES;
+  const __half* gsrc[NP];
+  size_t gstep[NP];     // source advance per 32-wide slab
+  int ldst[NP];         // halves from the stage base
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int q = wave * 4 + p, sl = q / (C::PA + C::PW), r = q % (C::PA + C::PW);
+  for (int p = 0; p < NP; ++p) {
+    const int q = wave * NP + p, sl = q / (C::PA + C::PW), r = q % (C::PA + C::PW);
     const int row16 = lane >> 2, c_log = (lane & 3) ^ swz(row16);
     ldst[p] = sl * C::SUB + r * 512;
     if (r < C::PA) {
@@ -674,8 +684,8 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
   auto issue = [&](int slot, int kt) {
     __half* base = smem + slot * C::STAGE_H;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(gsrc[p] + (size_t)(2 * kt) * gstep[p]), (lds_void*)(base + ldst[p]), 16, 0, 0);
+    for (int p = 0; p < NP; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gsrc[p] + (size_t)(C::SL * kt) * gstep[p]), (lds_void*)(base + ldst[p]), 16, 0, 0);
   };
 
   f32x4 acc[C::TI][C::TJ];
@@ -684,7 +694,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
 #pragma unroll
     for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fk = lane >> 4;
-  const int nst = K / SKS;
+  const int nst = K / (BK16 * C::SL);
 #pragma unroll
   for (int st = 0; st < SSTAGES - 1; ++st)
     if (st < nst) issue(st, st);
@@ -694,22 +704,22 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
                       : combine_row_stats(ep.stats_in + row, ep.n_part, M, 1.f / LN_FOLD_SCALE);
   }
   for (int kt = 0; kt < nst; ++kt) {
-    // stage kt has landed once at most the younger stages' pieces (4 per stage and wave) are outstanding
+    // stage kt has landed once at most the younger stages' pieces (NP per stage and wave) are outstanding
     const int ahead = min(SSTAGES - 2, nst - 1 - kt);
     switch (ahead) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NP) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NP) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NP) : "memory"); break;
     }
     __builtin_amdgcn_s_barrier();                       // everyone's pieces of stage kt landed; stage kt-1 fully consumed
     if (kt + SSTAGES - 1 < nst) issue((kt + SSTAGES - 1) % SSTAGES, kt + SSTAGES - 1);
     const __half* sb = smem + (kt % SSTAGES) * C::STAGE_H;
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < C::SL; ++sl) {
       const __half* s_ahi = sb + sl * C::SUB;
       const __half* s_alo = s_ahi + BM_ * BK16;
       const __half* s_w = s_ahi + 2 * BM_ * BK16;
@@ -734,58 +744,67 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, SSTAGES>::NW * 64)) gemm_f
         }
     }
   }
-  // ---- epilogue: the whole BM x BN tile through LDS (the ring is idle), then one (row, 8 columns) piece per lane
-  __syncthreads();
+  // ---- epilogue through LDS (the ring is idle): the tile - or, when it does not fit, one wave-row block of it after
+  // the other - then one (row, 8 columns) piece per lane and pass.  (Fetching the bias / LayerNorm-fold vectors /
+  // residual row of the piece BEFORE the K loop, to take them off the tail of the launch, was measured and is not
+  // faster.)
   float* s_c = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < C::TI; ++i)
-#pragma unroll
-    for (int j = 0; j < C::TJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        s_c[(wr * (C::TI * 16) + i * 16 + 4 * (lane >> 4) + e) * C::CLDS + wc * (C::TJ * 16) + j * 16 + (lane & 15)] = acc[i][j][e];
-  __syncthreads();
-  // one (row, 8 columns) piece per lane and pass.  (Fetching the bias / LayerNorm-fold vectors / residual row of the
-  // piece BEFORE the K loop, to take them off the tail of the launch, was measured and is slower: 830 vs 726 us for a
-  // one-request call - the early loads sit in front of the first operand pieces.)
   const bool wide = ep.out_hi == nullptr;
   const int l8 = lane & 7;
   const int ecol = l8 * (wide ? 4 : 8), ecol_b = wide ? ecol + 32 : ecol + 4;
   constexpr int P64 = BN_ / 64;                                      // 64-column pieces per tile row
+  constexpr int WROWS = C::TI * 16;                                  // rows of a wave
 #pragma unroll
-  for (int pi = 0; pi < BM_ * BN_ / 8 / (C::NW * 64); ++pi) {
-    const int idx = (pi * (C::NW * 64) + tid) >> 3;                  // (row, piece) index; the 8 lanes of a piece are consecutive
-    const int srow = idx / P64, pc = idx % P64;
-    const int grow = m0 + srow;
-    const int ccol = n0 + pc * 64 + ecol, ccol_b = n0 + pc * 64 + ecol_b;
-    if (grow >= M || ccol >= N) continue;
-    const float4 va = *reinterpret_cast<const float4*>(s_c + srow * C::CLDS + pc * 64 + ecol);
-    const float4 vb = *reinterpret_cast<const float4*>(s_c + srow * C::CLDS + pc * 64 + ecol_b);
-    const size_t o = (size_t)grow * N + ccol;
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    if (ep.resid) {
-      ra = *reinterpret_cast<const float4*>(ep.resid + o);
-      rb = *reinterpret_cast<const float4*>(ep.resid + o + (ecol_b - ecol));
+  for (int eh = 0; eh < C::EH; ++eh) {
+    __syncthreads();                                                 // ring / previous pass fully consumed
+    const int rbase = eh * C::EROWS;                                 // first tile row of this pass
+    if (C::EH == 1 || wr == eh) {
+      const int lrow0 = wr * WROWS - rbase;
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            s_c[(lrow0 + i * 16 + 4 * (lane >> 4) + e) * C::CLDS + wc * (C::TJ * 16) + j * 16 + (lane & 15)] = acc[i][j][e];
     }
-    float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
-    if (ep.bias) {
-      bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
-      bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
-    }
-    float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;    // LNP: gamma * scale; LNC: c_n
-    if (LNM != LN_NONE) {
-      const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
-      lnv_a = *reinterpret_cast<const float4*>(src + ccol);
-      lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
-      if (LNM == LNP) {
-        lnv_a.x *= LN_FOLD_SCALE; lnv_a.y *= LN_FOLD_SCALE; lnv_a.z *= LN_FOLD_SCALE; lnv_a.w *= LN_FOLD_SCALE;
-        lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
+    __syncthreads();
+#pragma unroll
+    for (int pi = 0; pi < C::EROWS * BN_ / 8 / (C::NW * 64); ++pi) {
+      const int idx = (pi * (C::NW * 64) + tid) >> 3;                // (row, piece) index; the 8 lanes of a piece are consecutive
+      const int lrow = idx / P64, pc = idx % P64;
+      const int srow = rbase + lrow;                                 // row inside the tile
+      const int grow = m0 + srow;
+      const int ccol = n0 + pc * 64 + ecol, ccol_b = n0 + pc * 64 + ecol_b;
+      if (grow >= M || ccol >= N) continue;
+      const float4 va = *reinterpret_cast<const float4*>(s_c + lrow * C::CLDS + pc * 64 + ecol);
+      const float4 vb = *reinterpret_cast<const float4*>(s_c + lrow * C::CLDS + pc * 64 + ecol_b);
+      const size_t o = (size_t)grow * N + ccol;
+      float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+      if (ep.resid) {
+        ra = *reinterpret_cast<const float4*>(ep.resid + o);
+        rb = *reinterpret_cast<const float4*>(ep.resid + o + (ecol_b - ecol));
       }
+      float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
+      if (ep.bias) {
+        bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
+        bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
+      }
+      float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;    // LNP: gamma * scale; LNC: c_n
+      if (LNM != LN_NONE) {
+        const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
+        lnv_a = *reinterpret_cast<const float4*>(src + ccol);
+        lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
+        if (LNM == LNP) {
+          lnv_a.x *= LN_FOLD_SCALE; lnv_a.y *= LN_FOLD_SCALE; lnv_a.z *= LN_FOLD_SCALE; lnv_a.w *= LN_FOLD_SCALE;
+          lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
+        }
+      }
+      float2 st2 = make_float2(0.f, 0.f);
+      if (LNM == LNC || RLN) st2 = s_stat[srow];
+      epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
+                               tn * P64 + pc);
     }
-    float2 st2 = make_float2(0.f, 0.f);
-    if (LNM == LNC || RLN) st2 = s_stat[srow];
-    epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
-                             tn * P64 + pc);
   }
 }
 
@@ -972,14 +991,20 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     static const int gm_narrow = [] { const char* e = getenv("LTR_GEMM_GM_NARROW"); return e ? atoi(e) : (GM_DEFAULT | 65536); }();
     const int gm = tiles_n <= 4 ? gm_narrow : gm_wide;
     // Small batches (a scheduler step with a few arrivals): the small-tile, deep-ring kernels (bit-identical results).
-    // LTR_GEMM_SMALL_M / LTR_GEMM_MID_M: row thresholds (0 switches a variant off; A/B knobs).
+    // LTR_GEMM_SMALL_M / LTR_GEMM_MID_M: row thresholds of the 32 x 64 / 64 x 128 tiles (0 switches a variant off; A/B
+    // knobs, profiles/r03_small_batch.txt).  A third configuration - the 128 x 256 tile behind a ring of four 32-wide
+    // stages at one workgroup per CU (SmallCfg<128, 256, 2, 4, 1, 4>, parity-green) - was measured for 1k-23k rows and
+    // is slower than both its neighbours everywhere (1,382 tokens: 2.21 vs 1.42 ms per call; 5,928: 3.31 vs 3.02;
+    // 23,078: 9.58 vs 8.61): not instantiated.
     static const int small_m = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 1024; }();
     static const int mid_m = [] { const char* e = getenv("LTR_GEMM_MID_M"); return e ? atoi(e) : 3072; }();
     static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 0; }();
-    if (g.K % SKS == 0 && (g.M <= small_m || g.M <= mid_m)) {
-      const bool sm = g.M <= small_m;
-      const int bm = sm ? 32 : 64, bnn = sm ? 64 : 128;
-      if (g.N % 64 == 0 && (sm || g.N % 128 == 0)) {
+    int cfg = -1;                                                    // 0: 32 x 64, 1: 64 x 128
+    if (g.K % 64 == 0 && g.N % 64 == 0 && g.M <= small_m) cfg = 0;
+    else if (g.K % 64 == 0 && g.N % 128 == 0 && g.M <= mid_m) cfg = 1;
+    if (cfg >= 0) {
+      const int bm = cfg == 0 ? 32 : 64, bnn = cfg == 0 ? 64 : 128;
+      {
         const int tm_ = (g.M + bm - 1) / bm, tn_ = g.N / bnn;
         // XCD grid: as many column ranges as keep an XCD's share of the weight matrix near 1.5 MB (and no more than
         // there are column tiles), the rest of the 8 XCDs split the rows.  map_mode 0: every XCD a row range.
@@ -994,27 +1019,28 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
           xm.per_xcd = a * b;                                          // range 0 is never the shorter one
         }
         dim3 sgrid(xm.per_xcd * NXCD);
-#define LTR_SMALL_LAUNCH(LN, RL, BMv, BNv, STv)                                                                            \
+#define LTR_SMALL_LAUNCH(LN, RL, BMv, BNv, WMv, WNv, SLv, STv)                                                             \
   do {                                                                                                                     \
-    typedef SmallCfg<BMv, BNv, STv> Cfg;                                                                                   \
+    typedef SmallCfg<BMv, BNv, WMv, WNv, SLv, STv> Cfg;                                                                    \
     static const bool attr_ok = [] {                                                                                       \
-      return hipFuncSetAttribute((const void*)gemm_f16s_small_kernel<LN, RL, BMv, BNv, STv>,                               \
+      return hipFuncSetAttribute((const void*)gemm_f16s_small_kernel<LN, RL, BMv, BNv, WMv, WNv, SLv, STv>,                \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) == hipSuccess;           \
     }();                                                                                                                   \
     (void)attr_ok;                                                                                                         \
-    gemm_f16s_small_kernel<LN, RL, BMv, BNv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(                              \
+    gemm_f16s_small_kernel<LN, RL, BMv, BNv, WMv, WNv, SLv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(               \
         (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, g.K, tm_, tn_, xm, ep);                \
   } while (0)
-#define LTR_SMALL_LN(BMv, BNv, STv)                                                                                        \
+#define LTR_SMALL_LN(...)                                                                                                  \
   do {                                                                                                                     \
-    if (rln) { if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, true, BMv, BNv, STv); else LTR_SMALL_LAUNCH(LN_NONE, true, BMv, BNv, STv); } \
-    else if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, false, BMv, BNv, STv);                                                      \
-    else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, false, BMv, BNv, STv);                                                      \
-    else LTR_SMALL_LAUNCH(LN_NONE, false, BMv, BNv, STv);                                                                  \
+    if (rln) { if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, true, __VA_ARGS__); else LTR_SMALL_LAUNCH(LN_NONE, true, __VA_ARGS__); } \
+    else if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, false, __VA_ARGS__);                                                        \
+    else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, false, __VA_ARGS__);                                                        \
+    else LTR_SMALL_LAUNCH(LN_NONE, false, __VA_ARGS__);                                                                    \
   } while (0)
         // (a ring of eight stages for grids of at most one workgroup per CU was measured and is slower: fc2 of a
         // one-request call 21.7 vs 15.7 us, profiles/r03_small_batch.txt)
-        if (sm) LTR_SMALL_LN(32, 64, 4); else LTR_SMALL_LN(64, 128, 4);
+        if (cfg == 0) LTR_SMALL_LN(32, 64, 2, 2, 2, 4);
+        else LTR_SMALL_LN(64, 128, 2, 4, 2, 4);
 #undef LTR_SMALL_LN
 #undef LTR_SMALL_LAUNCH
         LTR_LAUNCH_CHECK();
