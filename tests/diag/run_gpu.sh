@@ -1,3 +1,12 @@
-O=gpurun_out/r03_n; mkdir -p $O
-LTR_GEMM_DEEP_TILES=600 LTR_GEMM_DEEP_M=1024 python -m pytest tests/test_gpu_small_batches.py tests/test_gpu_gemm_epilogue.py -m gpu -q -k "not latency" > $O/t1.log 2>&1; tail -3 $O/t1.log
-for cfg in "0 0" "1024 320" "1024 600" "1024 1200" "3072 600" "3072 1200" "512 600"; do set -- $cfg; echo "DEEP_M=$1 DEEP_TILES=$2"; LTR_GEMM_DEEP_M=$1 LTR_GEMM_DEEP_TILES=$2 python tests/diag/small_call_profile.py 4 8 16 32 64 128 256 2>/dev/null | cut -c1-100; done | tee $O/ab_deep.txt
+O=gpurun_out/r03_k; mkdir -p $O
+python -m pytest tests/test_train_step.py -m gpu -q -s > $O/t_train.log 2>&1; grep -E "^FAILED|fit:|passed|failed|AssertionError|ListMLE" $O/t_train.log | tail -12
+python bench.py --train --steps 3 --warmup 1 2>/dev/null | tee $O/train_bench2.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1),'ms', round(d['exact_f32_ms_per_step'],1), round(d['value']), 'tok/s', round(d['algorithmic_tflops'],1), 'TFLOP/s')"
+python bench.py --train --train-slate 128 --steps 3 --warmup 1 2>/dev/null | tee -a $O/train_bench2.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1),'ms', round(d['exact_f32_ms_per_step'],1), round(d['value']), 'tok/s', round(d['algorithmic_tflops'],1), 'TFLOP/s')"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/prof -o k -- python $GRAFT_REPO_ROOT/bench.py --train --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
+python $GRAFT_REPO_ROOT/profiles/summarize_rocpd.py $(find $GRAFT_REPO_ROOT/$O/prof -name "*.db" | head -1) $GRAFT_REPO_ROOT/$O/train_kernel_stats.csv | head -14
+find $GRAFT_REPO_ROOT/$O -name "*.db" -delete

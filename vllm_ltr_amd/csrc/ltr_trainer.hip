@@ -376,17 +376,24 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 constexpr int BQ = 64;    // rows per block of the work list (attn_blocks_kernel with qb = 64)
 constexpr int BT = 32;    // rows staged in LDS per step
 
+// Workgroup = a block of 64 rows (lane = row) x BW waves: the waves deal the tiles of the OTHER dimension among themselves
+// (round-robin), each with its own LDS staging area, and their partial sums are added up in wave order at the end.
+// (Round 2 ran one wave per block: the launch then lasted as long as the serial loop of the longest prompt - 1,024 keys
+// x 192 FMAs per lane - while three quarters of the chip had nothing to do: 410 + 750 us per layer for a 32-prompt slate.)
+constexpr int BW = 4;
+
 // one lane per query: dQ and D
-__global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                         const float* __restrict__ dout, const float* __restrict__ lse2,
-                                                         const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc,
-                                                         int n_req, int H, float scale, float* __restrict__ dqkv,
-                                                         float* __restrict__ Dq) {
-  __shared__ __attribute__((aligned(16))) float s_k[BT * D];
-  __shared__ __attribute__((aligned(16))) float s_v[BT * D];
+__global__ void __launch_bounds__(64 * BW) attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                              const float* __restrict__ dout, const float* __restrict__ lse2,
+                                                              const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc,
+                                                              int n_req, int H, float scale, float* __restrict__ dqkv,
+                                                              float* __restrict__ Dq) {
+  __shared__ __attribute__((aligned(16))) float smem[BW * 2 * BT * D];          // per wave: s_k | s_v; reused for the reduction
   const int b = blockIdx.x;
   if (b >= blk_start[n_req]) return;
-  const int head = blockIdx.y, lane = threadIdx.x, nh = H / D;
+  const int head = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nh = H / D;
+  float* s_k = smem + wave * 2 * BT * D;
+  float* s_v = s_k + BT * D;
   const int4 desc = blk_desc[b];
   const int q0 = desc.y, t0 = desc.z, L = desc.w;
   const int qi = q0 + lane;
@@ -403,18 +410,19 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const float* __restrict
 #pragma unroll
     for (int d = 0; d < D; ++d) { q[d] = qp[d] * sl2; dO[d] = dp[d]; dsum += dp[d] * op[d]; dq[d] = 0.f; }
     lse = lse2[row * nh + head];
-    if (valid) Dq[row * nh + head] = dsum;
+    if (valid && wave == 0) Dq[row * nh + head] = dsum;
   }
   const int kend = min(L, q0 + BQ);
-  for (int kt = 0; kt < kend; kt += BT) {
-    __syncthreads();
+  for (int kt = wave * BT; kt < kend; kt += BW * BT) {        // this wave's key tiles
+    __builtin_amdgcn_wave_barrier();                            // (wave-private staging: no workgroup barrier)
     for (int idx = lane; idx < BT * D / 4; idx += 64) {
       const int key = idx >> 4, d4 = (idx & 15) * 4;
       const float* base = qkv + (size_t)(t0 + min(kt + key, L - 1)) * ld + head * D + d4;
       *reinterpret_cast<float4*>(s_k + key * D + d4) = *reinterpret_cast<const float4*>(base + H);
       *reinterpret_cast<float4*>(s_v + key * D + d4) = *reinterpret_cast<const float4*>(base + 2 * H);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < BT; ++j) {
       const int kj = kt + j;
       if (kj >= kend) break;                               // uniform
@@ -429,23 +437,38 @@ __global__ void __launch_bounds__(64) attn_bwd_dq_kernel(const float* __restrict
       for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
     }
   }
-  if (!valid) return;
+  // partial dq of the waves -> wave 0, added in wave order (fixed order: deterministic)
+  __syncthreads();
+  float* red = smem;                                         // [BW - 1][D][64 lanes] = 48 KiB of the 64 KiB
+  if (wave > 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) red[((wave - 1) * D + d) * 64 + lane] = dq[d];
+  }
+  __syncthreads();
+  if (wave != 0 || !valid) return;
   float* out = dqkv + (size_t)(t0 + qi) * ld + head * D;
 #pragma unroll
-  for (int d = 0; d < D; ++d) out[d] = dq[d] * scale;
+  for (int d = 0; d < D; ++d) {
+    float v = dq[d];
+#pragma unroll
+    for (int w = 0; w < BW - 1; ++w) v += red[(w * D + d) * 64 + lane];
+    out[d] = v * scale;
+  }
 }
 
-// one lane per key: dV (pass 0) and dK (pass 1); queries streamed through LDS
-__global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                          const float* __restrict__ lse2, const float* __restrict__ Dq,
-                                                          const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc,
-                                                          int n_req, int H, float scale, float* __restrict__ dqkv) {
-  __shared__ __attribute__((aligned(16))) float s_q[BT * D];
-  __shared__ __attribute__((aligned(16))) float s_do[BT * D];
-  __shared__ float s_lse[BT], s_dq[BT];
+// one lane per key: dV (pass 0) and dK (pass 1); queries streamed through LDS, the query tiles dealt to the waves
+__global__ void __launch_bounds__(64 * BW) attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse2, const float* __restrict__ Dq,
+                                                               const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc,
+                                                               int n_req, int H, float scale, float* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) float smem[BW * (2 * BT * D + 2 * BT)];   // per wave: s_q | s_do | s_lse | s_dq
   const int b = blockIdx.x;
   if (b >= blk_start[n_req]) return;
-  const int head = blockIdx.y, lane = threadIdx.x, nh = H / D;
+  const int head = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nh = H / D;
+  float* s_q = smem + wave * (2 * BT * D + 2 * BT);
+  float* s_do = s_q + BT * D;
+  float* s_lse = s_do + BT * D;
+  float* s_dq = s_lse + BT;
   const int4 desc = blk_desc[b];
   const int k0 = desc.y, t0 = desc.z, L = desc.w;
   const int ki = k0 + lane;
@@ -461,8 +484,8 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const float* __restric
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
-    for (int qt = k0; qt < L; qt += BT) {                  // queries >= the first key of this block
-      __syncthreads();
+    for (int qt = k0 + wave * BT; qt < L; qt += BW * BT) {   // this wave's query tiles (queries >= the first key of this block)
+      __builtin_amdgcn_wave_barrier();
       for (int idx = lane; idx < BT * D / 4; idx += 64) {
         const int qq = idx >> 4, d4 = (idx & 15) * 4;
         const size_t row = (size_t)(t0 + min(qt + qq, L - 1));
@@ -476,7 +499,8 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const float* __restric
         s_lse[lane] = lse2[row * nh + head];
         s_dq[lane] = Dq[row * nh + head];
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
       for (int j = 0; j < BT; ++j) {
         const int qj = qt + j;
         if (qj >= L) break;                                // uniform
@@ -496,13 +520,27 @@ __global__ void __launch_bounds__(64) attn_bwd_dkv_kernel(const float* __restric
         }
       }
     }
-    if (valid) {
+    // partial sums of the waves -> wave 0, in wave order
+    __syncthreads();
+    float* red = smem;                                       // [BW - 1][D][64] floats = 48 KiB (the staging areas are idle)
+    if (wave > 0) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) red[((wave - 1) * D + d) * 64 + lane] = acc[d];
+    }
+    __syncthreads();
+    if (wave == 0 && valid) {
       // pass 0 -> dV; pass 1 -> dK = scale sum dS q = sum dS (q scale log2e) / log2e
       float* out = dqkv + (size_t)(t0 + ki) * ld + (pass == 0 ? 2 * H : H) + head * D;
       const float f = pass == 0 ? 1.f : 0.6931471805599453f;
 #pragma unroll
-      for (int d = 0; d < D; ++d) out[d] = acc[d] * f;
+      for (int d = 0; d < D; ++d) {
+        float v = acc[d];
+#pragma unroll
+        for (int w = 0; w < BW - 1; ++w) v += red[(w * D + d) * 64 + lane];
+        out[d] = v * f;
+      }
     }
+    __syncthreads();                                         // the reduction area is the next pass's staging area
   }
 }
 
@@ -867,9 +905,9 @@ int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
     RC(gemm_nn(c, dproj, P(LTR_WL_OUT_W), nullptr, dao, T, H, H));
     {
       dim3 grid(T / BQ + N, d.num_heads);
-      attn_bwd_dq_kernel<<<grid, 64, 0, s>>>(L.qkv, L.ao, dao, L.lse, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig, c.ws.Dq);
+      attn_bwd_dq_kernel<<<grid, 64 * BW, 0, s>>>(L.qkv, L.ao, dao, L.lse, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig, c.ws.Dq);
       LTR_LAUNCH_CHECK();
-      attn_bwd_dkv_kernel<<<grid, 64, 0, s>>>(L.qkv, dao, L.lse, c.ws.Dq, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig);
+      attn_bwd_dkv_kernel<<<grid, 64 * BW, 0, s>>>(L.qkv, dao, L.lse, c.ws.Dq, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig);
       LTR_LAUNCH_CHECK();
     }
     RC(gemm_tn(c, c.ws.dbig, qkv_in, G(LTR_WL_QKV_W), T, 3 * H, H));
