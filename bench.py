@@ -447,7 +447,7 @@ def main():
                 if v["launches"] == 0:
                     continue
                 rate = v["work"] / (v["ms"] * 1e-3)
-                if k in ("gemm", "attn"):
+                if k in ("gemm", "attn", "gemm_small"):
                     kernels[k] = dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
                                       tflops=rate / 1e12)
                 else:
@@ -486,6 +486,8 @@ def main():
                     "traffic_source": traffic_src if traffic is not None else
                     {"stale": True, "reason": "profiles/gemm_traffic.json was not taken on the current kernel sources",
                      "file": traffic_src, "current_kernel_sha16": sha},
+                    # launches of THIS kernel only (the 128 x 256-tile one: the rocprofv3 row of the same name); the compact
+                    # last-token rows of each pass run on the small-batch kernels, timed apart as kernels.gemm_small
                     "launches_per_step": gemm["launches"] // max(args.steps, 1),
                     "avg_launch_ms": avg_launch_s * 1e3,
                     # the same kernel against the OTHER roof: PMC bytes per launch / live launch time, over 8 TB/s.

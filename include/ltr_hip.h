@@ -269,7 +269,9 @@ int ltr_head_score(ltr_head_handle h, const float* hidden, const int32_t* row_in
  * per class and optionally resets.  work = algorithmic FLOPs (GEMM: 2*M*N*K; ATTN: causal
  * 2*L^2*H per layer and request) or algorithmic bytes (EMBED, LN, POOL) as defined in
  * DESIGN.md. */
-enum { LTR_K_GEMM = 0, LTR_K_ATTN = 1, LTR_K_EMBED = 2, LTR_K_LN = 3, LTR_K_POOL = 4, LTR_K_COUNT = 5 };
+/* LTR_K_GEMM: launches of the large-tile kernel (gemm_f16s_kernel / gemm_f32_kernel); LTR_K_GEMM_SMALL: the small-batch
+ * kernels (compact last-token rows of a pass, small calls) */
+enum { LTR_K_GEMM = 0, LTR_K_ATTN = 1, LTR_K_EMBED = 2, LTR_K_LN = 3, LTR_K_POOL = 4, LTR_K_GEMM_SMALL = 5, LTR_K_COUNT = 6 };
 typedef struct ltr_profile_stats {
   double ms[8];        /* summed kernel time per class   */
   double work[8];      /* summed algorithmic FLOPs/bytes */

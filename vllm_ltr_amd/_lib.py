@@ -60,7 +60,7 @@ class ProfileStats(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("work", C.c_double * 8), ("launches", C.c_int64 * 8)]
 
 
-PROFILE_KINDS = ("gemm", "attn", "embed", "ln", "pool")
+PROFILE_KINDS = ("gemm", "attn", "embed", "ln", "pool", "gemm_small")
 
 _lib = None
 _load_lock = threading.Lock()

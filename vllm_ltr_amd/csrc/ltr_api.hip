@@ -204,7 +204,8 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   float* hb = ws.h;
   AOp ab = ws.a, fb = ws.f;
   auto gemm = [&](const GemmArgs& g) {
-    ProfScope p(m, LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
+    // the dominant kernel (128 x 256 tiles) and the small-batch kernels are timed as separate classes
+    ProfScope p(m, wd == LTR_W_F16 && gemm_small_config(g) >= 0 ? LTR_K_GEMM_SMALL : LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
     return launch_gemm(wd, g, s);
   };
   auto lnorm = [&](int rows, const float* x, const float* gw_, const float* gb_, float* of, AOp oo) {

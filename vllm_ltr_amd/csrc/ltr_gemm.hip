@@ -946,6 +946,18 @@ int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s, 
   return LTR_OK;
 }
 
+namespace {
+int small_m_threshold() { static const int v = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 1024; }(); return v; }
+int mid_m_threshold() { static const int v = [] { const char* e = getenv("LTR_GEMM_MID_M"); return e ? atoi(e) : 3072; }(); return v; }
+}  // namespace
+
+// which F16 kernel a GEMM of this shape runs on: -1 the 128 x 256 kernel, 0 the 32 x 64, 1 the 64 x 128 small-batch kernel
+int gemm_small_config(const GemmArgs& g) {
+  if (g.K % 64 == 0 && g.N % 64 == 0 && g.M <= small_m_threshold()) return 0;
+  if (g.K % 64 == 0 && g.N % 128 == 0 && g.M <= mid_m_threshold()) return 1;
+  return -1;
+}
+
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   if (g.M == 0) return LTR_OK;
   const int kmult = wdtype == LTR_W_F16 ? BK16 : BK32;
@@ -996,12 +1008,8 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     // stages at one workgroup per CU (SmallCfg<128, 256, 2, 4, 1, 4>, parity-green) - was measured for 1k-23k rows and
     // is slower than both its neighbours everywhere (1,382 tokens: 2.21 vs 1.42 ms per call; 5,928: 3.31 vs 3.02;
     // 23,078: 9.58 vs 8.61): not instantiated.
-    static const int small_m = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 1024; }();
-    static const int mid_m = [] { const char* e = getenv("LTR_GEMM_MID_M"); return e ? atoi(e) : 3072; }();
     static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 0; }();
-    int cfg = -1;                                                    // 0: 32 x 64, 1: 64 x 128
-    if (g.K % 64 == 0 && g.N % 64 == 0 && g.M <= small_m) cfg = 0;
-    else if (g.K % 64 == 0 && g.N % 128 == 0 && g.M <= mid_m) cfg = 1;
+    const int cfg = gemm_small_config(g);                            // 0: 32 x 64, 1: 64 x 128
     if (cfg >= 0) {
       const int bm = cfg == 0 ? 32 : 64, bnn = cfg == 0 ? 64 : 128;
       {

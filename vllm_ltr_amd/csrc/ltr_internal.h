@@ -80,6 +80,8 @@ struct GemmArgs {
 
 // launchers (each in its own .hip file)
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
+// F16 mode: -1 = this shape runs on the 128 x 256 kernel (gemm_f16s_kernel), 0 / 1 = on a small-batch kernel (profiling)
+int gemm_small_config(const GemmArgs& g);
 // n_src < N: the source has n_src rows, the image is padded with zero rows up to N (N a multiple of 64 for launch_gemm)
 int launch_pack_weight(const void* src_f16 /*[N,K]*/, void* dst_f16 /*[K/32][N][32]*/, int N, int K, hipStream_t s,
                        int n_src = -1);
