@@ -267,3 +267,20 @@ def test_bench_strong_scaling_mode_two_ranks_one_device():
     assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["queue_total"] == 4096
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["p50_steady_new_latency_ms"]["16"] > 0
     assert 0 < out["config"]["tokens_rank0_shard"] < out["config"]["tokens_total"]
+
+
+def test_rccl_backend_collectives_single_rank():
+    """The production backend ("nccl" = RCCL) on the one GPU of the box.  RCCL refuses two ranks on one device
+    ("Duplicate GPU detected"), so the multi-rank tests above run the control plane over gloo; this one runs every
+    collective the N-rank path issues - the padded score all-gather of `gather_scores` (device buffers, compaction into
+    `out`), the int32 MAX all-reduce of `ShardedScorer.any_rank`, the f64 MAX all-reduce of the bench clock, the
+    not-sharded broadcast, the barrier - through RCCL itself with `init_process_group("nccl", device_id=...)` at world
+    size 1: the API usage (dtypes, device tensors, in-place outputs) is what a first 8-GPU run would otherwise meet cold."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "rccl_probe.py"), "1"], capture_output=True,
+                       text=True, timeout=600, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "rank 0/1: gather [0.0, 1.0, 2.0, 3.0, 4.0] max-rank 0 max-f64 1.5 bcast 1.0" in r.stdout, r.stdout[-1000:]
+    assert "ok world 1" in r.stdout
