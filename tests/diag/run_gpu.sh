@@ -1,6 +1,2 @@
-B="python bench.py --no-cpu-baseline --no-unfused --no-strong --no-class-head --steady-new 0 --steps 5 --warmup 2"
-for i in 1 2; do
-for o in 0 1; do
-echo "ORDER=$o"; LTR_ATTN_ORDER=$o $B 2>/dev/null | python -c "import json,sys; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(b['ms_per_step'], b['kernels']['attn'], b['kernels']['gemm']['ms_per_step'])"
-done; done
-timeout 900 python -m pytest tests/test_gpu_attention.py tests/test_gpu_scorer.py -x -q 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_train_step.py -x -q 2>&1 | tail -5
+python bench.py --train --train-slate 32 --steps 5 --warmup 2 2>/dev/null | tail -1 | cut -c1-900

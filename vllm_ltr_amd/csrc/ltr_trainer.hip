@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "ltr_internal.h"
@@ -130,16 +131,55 @@ __global__ void __launch_bounds__(256) split_operand_dup_kernel(const float* __r
   *reinterpret_cast<uint4*>(lo + second + i * 8) = *reinterpret_cast<const uint4*>(l);
 }
 
+// The same two operand forms from a TRANSPOSED source: S [R, C] row-major f32, operand row c = column c of S, contraction
+// index = row of S, zero-padded to Rp (the weight-gradient GEMMs contract over the tokens: dW = dY^T X; the data-gradient
+// GEMMs need W^T).  Replaces a transpose_pad launch + a second pass over the transposed copy.  One workgroup: 32 rows
+// (one K-slab) x 64 columns of S through LDS; one 16-byte piece (operand row, 8 contraction elements) per thread.
+//   ROLE_A: planes hi / lo of [A | A]  (dst = hi plane, dst2 = lo plane, each [2 Rp / 32][C][32])
+//   else  : image of [Bh | Bl]         (dst [2 Rp / 32][C][32]: hi in slab s, lo in slab s + Rp / 32)
+template <bool ROLE_A>
+__global__ void __launch_bounds__(256) split_T_kernel(const float* __restrict__ S, __half* __restrict__ dst,
+                                                      __half* __restrict__ dst2, int R, int C, int Rp,
+                                                      const float* __restrict__ amax) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 64, slab = blockIdx.y, r0 = slab * 32;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int k = 0; k < 32; k += 16) {
+    const int r = r0 + ty + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) v = *reinterpret_cast<const float4*>(S + (size_t)r * C + c0 + tx * 4);
+    tile[ty + k][tx * 4 + 0] = v.x; tile[ty + k][tx * 4 + 1] = v.y; tile[ty + k][tx * 4 + 2] = v.z; tile[ty + k][tx * 4 + 3] = v.w;
+  }
+  __syncthreads();
+  const int crow = threadIdx.x >> 2, kc = threadIdx.x & 3;
+  const float sc = split_scale(*amax);
+  __half h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split_f16(tile[kc * 8 + e][crow] * sc, h[e], l[e]);
+  const size_t piece = ((size_t)slab * C + c0 + crow) * 32 + kc * 8;       // halves
+  const size_t second = (size_t)(Rp / 32) * C * 32;
+  if (ROLE_A) {
+    *reinterpret_cast<uint4*>(dst + piece) = *reinterpret_cast<const uint4*>(h);
+    *reinterpret_cast<uint4*>(dst + second + piece) = *reinterpret_cast<const uint4*>(h);
+    *reinterpret_cast<uint4*>(dst2 + piece) = *reinterpret_cast<const uint4*>(l);
+    *reinterpret_cast<uint4*>(dst2 + second + piece) = *reinterpret_cast<const uint4*>(l);
+  } else {
+    *reinterpret_cast<uint4*>(dst + piece) = *reinterpret_cast<const uint4*>(h);
+    *reinterpret_cast<uint4*>(dst + second + piece) = *reinterpret_cast<const uint4*>(l);
+  }
+}
+
 // out = (ReLU)(raw / (sa sb) + bias) + resid: undoes the operand scales of the split GEMM (exact powers of two) and
 // applies what the f32 GEMM's epilogue applies; optionally also writes the result as row-major hi | lo planes (QKV for
 // the MFMA attention).  8 consecutive columns per thread.
-__global__ void __launch_bounds__(256) gemm_finish_kernel(const float* __restrict__ raw, const float* __restrict__ amax2,
-                                                          const float* __restrict__ bias, const float* resid, float* out,
+__global__ void __launch_bounds__(256) gemm_finish_kernel(const float* __restrict__ raw, const float* __restrict__ amax_a,
+                                                          const float* __restrict__ amax_b, const float* __restrict__ bias, const float* resid, float* out,
                                                           size_t n8, int N, int relu, __half* __restrict__ p_hi,
                                                           __half* __restrict__ p_lo) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
-  const float inv = 1.f / (split_scale(amax2[0]) * split_scale(amax2[1]));
+  const float inv = 1.f / (split_scale(*amax_a) * split_scale(*amax_b));
   const int col = (int)((i * 8) % N);
   float v[8];
   *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(raw + i * 8);
@@ -657,64 +697,114 @@ struct Ctx {
   TrainWs ws;
   int T, N;
   bool eval = false;      // predictor.model.eval() (trainer.py:171): no dropout, forward only
-  int n_gemm = 0;         // split GEMMs so far in this step (index into ws.scales)
+  int n_slot = 0;         // max|x| slots handed out so far in this step (ws.scales)
+  // max|x| of tensors that do not change for the rest of the step (weights, saved activations), by address: the
+  // backward meets every forward operand again (X of dW = dY^T X, W of dX = dY W) and reuses its slot
+  std::unordered_map<const void*, float*> amax_cache;
 };
 
-// C[M, N] = A[M, K] B[N, K]^T (+ bias)(ReLU)(+ resid), all f32 in memory
-int gemm_nt(Ctx& c, const float* A, const float* B, const float* bias, const float* resid, float* out, int M, int N, int K,
-            int relu, AOp* planes = nullptr /*fp16 path: also write the result as row-major hi | lo planes; cleared if it did not*/) {
-  hipStream_t s = c.s;
-  GemmArgs g{};
-  g.bias = bias; g.resid = resid; g.out_f32 = out; g.M = M; g.N = N; g.relu = relu;
-  if (!c.t->use_f32 && K % 32 == 0 && N % 64 == 0) {
-    // split both operands: [A | A] [Bh | Bl]^T over K' = 2K on the split-fp16 kernel (Ah Bh + Al Bh + Ah Bl + Al Bl),
-    // each operand scaled into fp16's range by a power of two first (split_scale), undone by gemm_finish_kernel
-    if (c.n_gemm >= MAX_GEMMS) { set_error("ltr_train_step: more than %d GEMMs in one step", MAX_GEMMS); return LTR_E_INVAL; }
-    float* sl = c.ws.scales + 2 * (c.n_gemm++);
-    amax_kernel<<<(unsigned)std::min<size_t>(((size_t)M * K + 4095) / 4096, 2048), 256, 0, s>>>(A, (size_t)M * K, sl);
-    amax_kernel<<<(unsigned)std::min<size_t>(((size_t)N * K + 4095) / 4096, 2048), 256, 0, s>>>(B, (size_t)N * K, sl + 1);
-    __half* ah = reinterpret_cast<__half*>(c.ws.opa);
-    __half* al = ah + (size_t)M * 2 * K;
-    const size_t apieces = (size_t)M * K / 8;
-    split_operand_dup_kernel<<<(unsigned)((apieces + 255) / 256), 256, 0, s>>>(A, ah, al, M, K, sl);
-    const size_t pieces = (size_t)N * K / 4;
-    split_pack_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>(B, reinterpret_cast<__half*>(c.ws.wb), N, K, sl + 1);
-    LTR_LAUNCH_CHECK();
-    GemmArgs r{};
-    r.a = AOp{ah, al}; r.w = c.ws.wb; r.out_f32 = c.ws.gtmp; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
-    int rc = launch_gemm(LTR_W_F16, r, s);
-    if (rc) return rc;
-    const size_t n8 = (size_t)M * N / 8;
-    gemm_finish_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, sl, bias, resid, out, n8, N, relu,
-                                                                   planes ? (__half*)planes->hi : nullptr,
-                                                                   planes ? (__half*)planes->lo : nullptr);
-    LTR_LAUNCH_CHECK();
-    return LTR_OK;
+// slot holding max|x| of p[0..n) (device, filled on the stream).  `stable`: p keeps its contents until the step ends.
+float* amax_of(Ctx& c, const float* p, size_t n, bool stable) {
+  if (stable) {
+    auto it = c.amax_cache.find(p);
+    if (it != c.amax_cache.end()) return it->second;
   }
-  if (planes) *planes = AOp{nullptr, nullptr};
-  g.a = AOp{(void*)A, nullptr}; g.w = B; g.K = K;
-  return launch_gemm(LTR_W_F32, g, s);
+  if (c.n_slot >= 2 * MAX_GEMMS) { set_error("ltr_train_step: more than %d GEMM operands in one step", 2 * MAX_GEMMS); return nullptr; }
+  float* sl = c.ws.scales + c.n_slot++;
+  amax_kernel<<<(unsigned)std::min<size_t>((n + 4095) / 4096, 2048), 256, 0, c.s>>>(p, n, sl);
+  if (stable) c.amax_cache[p] = sl;
+  return sl;
 }
+
+// One operand of a split GEMM: `rows` x `kr` logical matrix (contraction along kr).  !trans: p is [rows, kr] row-major;
+// trans: p is [kr, rows] row-major (the operand is p^T).  amax: its max|x| slot if the caller already has one.
+struct Opnd { const float* p; int rows, kr; bool trans, stable; float* amax; };
+
 int transpose_pad(const float* in, int R, int C, int Rp, float* out, hipStream_t s) {
   dim3 grid((C + 31) / 32, (Rp + 31) / 32);
   transpose_pad_kernel<<<grid, 256, 0, s>>>(in, R, C, Rp, out);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }
-// dX[M, K] = (resid) + dY[M, N] W[N, K]
-int gemm_nn(Ctx& c, const float* dY, const float* W, const float* resid, float* dX, int M, int N, int K) {
+
+// C[M, N] = A B^T (+ bias)(ReLU)(+ resid) with A = a (M x K), B = b (N x K), f32 in memory, on the split-fp16 MFMA kernel:
+// [A | A] [Bh | Bl]^T over K' = 2K (Ah Bh + Al Bh + Ah Bl + Al Bl), each operand scaled into fp16's range by a power of
+// two first (split_scale), undone by gemm_finish_kernel.  Per operand ONE preparation kernel (transposing or not).
+bool split_ok(const Ctx& c, const Opnd& a, const Opnd& b) {
+  if (c.t->use_f32 || b.rows % 64) return false;
+  if (a.trans && a.rows % 64) return false;
+  if (!a.trans && a.kr % 32) return false;
+  if (!b.trans && b.kr % 32) return false;
+  return true;
+}
+int gemm_split(Ctx& c, Opnd a, Opnd b, const float* bias, const float* resid, float* out, int relu, AOp* planes) {
+  hipStream_t s = c.s;
+  const int M = a.rows, N = b.rows, K = (a.kr + 31) / 32 * 32;
+  if (!a.amax) a.amax = amax_of(c, a.p, (size_t)a.rows * a.kr, a.stable);
+  if (!b.amax) b.amax = amax_of(c, b.p, (size_t)b.rows * b.kr, b.stable);
+  if (!a.amax || !b.amax) return LTR_E_INVAL;
+  __half* ah = reinterpret_cast<__half*>(c.ws.opa);
+  __half* al = ah + (size_t)M * 2 * K;
+  if (a.trans) {
+    split_T_kernel<true><<<dim3(M / 64, K / 32), 256, 0, s>>>(a.p, ah, al, a.kr, M, K, a.amax);
+  } else {
+    const size_t apieces = (size_t)M * K / 8;
+    split_operand_dup_kernel<<<(unsigned)((apieces + 255) / 256), 256, 0, s>>>(a.p, ah, al, M, K, a.amax);
+  }
+  if (b.trans) {
+    split_T_kernel<false><<<dim3(N / 64, K / 32), 256, 0, s>>>(b.p, reinterpret_cast<__half*>(c.ws.wb), nullptr, b.kr, N, K, b.amax);
+  } else {
+    const size_t pieces = (size_t)N * K / 4;
+    split_pack_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>(b.p, reinterpret_cast<__half*>(c.ws.wb), N, K, b.amax);
+  }
+  LTR_LAUNCH_CHECK();
+  GemmArgs r{};
+  r.a = AOp{ah, al}; r.w = c.ws.wb; r.out_f32 = c.ws.gtmp; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
+  int rc = launch_gemm(LTR_W_F16, r, s);
+  if (rc) return rc;
+  const size_t n8 = (size_t)M * N / 8;
+  gemm_finish_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, a.amax, b.amax, bias, resid, out, n8, N, relu,
+                                                                 planes ? (__half*)planes->hi : nullptr,
+                                                                 planes ? (__half*)planes->lo : nullptr);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+// C[M, N] = A[M, K] B[N, K]^T (+ bias)(ReLU)(+ resid), all f32 in memory.  Forward operands: both stable for the step.
+int gemm_nt(Ctx& c, const float* A, const float* B, const float* bias, const float* resid, float* out, int M, int N, int K,
+            int relu, AOp* planes = nullptr /*fp16 path: also write the result as row-major hi | lo planes; cleared if it did not*/) {
+  const Opnd a{A, M, K, false, true, nullptr}, b{B, N, K, false, true, nullptr};
+  if (split_ok(c, a, b)) return gemm_split(c, a, b, bias, resid, out, relu, planes);
+  if (planes) *planes = AOp{nullptr, nullptr};
+  GemmArgs g{};
+  g.bias = bias; g.resid = resid; g.out_f32 = out; g.M = M; g.N = N; g.relu = relu;
+  g.a = AOp{(void*)A, nullptr}; g.w = B; g.K = K;
+  return launch_gemm(LTR_W_F32, g, c.s);
+}
+// dX[M, K] = (resid) + dY[M, N] W[N, K]        (dy_amax: max|dY| slot shared with the weight-gradient GEMM of the same dY)
+int gemm_nn(Ctx& c, const float* dY, const float* W, const float* resid, float* dX, int M, int N, int K, float* dy_amax) {
+  const Opnd a{dY, M, N, false, false, dy_amax}, b{W, K, N, true, true, nullptr};
+  if (split_ok(c, a, b)) return gemm_split(c, a, b, nullptr, resid, dX, 0, nullptr);
   int rc = transpose_pad(W, N, K, N, c.t->wT, c.s);          // W^T [K, N]
   if (rc) return rc;
-  return gemm_nt(c, dY, c.t->wT, nullptr, resid, dX, M, K, N, 0);
+  GemmArgs g{};
+  g.resid = resid; g.out_f32 = dX; g.M = M; g.N = K; g.K = N; g.a = AOp{(void*)dY, nullptr}; g.w = c.t->wT;
+  return launch_gemm(LTR_W_F32, g, c.s);
 }
 // dW[N, K] = dY[M, N]^T X[M, K]
-int gemm_tn(Ctx& c, const float* dY, const float* X, float* dW, int M, int N, int K) {
+int gemm_tn(Ctx& c, const float* dY, const float* X, float* dW, int M, int N, int K, float* dy_amax) {
+  const Opnd a{dY, N, M, true, false, dy_amax}, b{X, K, M, true, true, nullptr};
+  if (split_ok(c, a, b)) return gemm_split(c, a, b, nullptr, nullptr, dW, 0, nullptr);
   const int Mp = (M + 31) / 32 * 32;
   int rc = transpose_pad(dY, M, N, Mp, c.ws.t1, c.s);        // [N, Mp]
   if (rc) return rc;
   if ((rc = transpose_pad(X, M, K, Mp, c.ws.t2, c.s))) return rc;   // [K, Mp]
-  return gemm_nt(c, c.ws.t1, c.ws.t2, nullptr, nullptr, dW, N, K, Mp, 0);
+  GemmArgs g{};
+  g.out_f32 = dW; g.M = N; g.N = K; g.K = Mp; g.a = AOp{c.ws.t1, nullptr}; g.w = c.ws.t2;
+  return launch_gemm(LTR_W_F32, g, c.s);
 }
+// max|dY| once for the two GEMMs that consume the same gradient (nullptr on the exact-f32 path: nothing is scaled there)
+float* grad_amax(Ctx& c, const float* dY, size_t n) { return c.t->use_f32 ? nullptr : amax_of(c, dY, n, false); }
 int colsum(Ctx& c, const float* x, const float* y, int M, int N, float* out) {
   const int nb = (M + CS_ROWS - 1) / CS_ROWS;
   dim3 grid((N + 255) / 256, nb);
@@ -838,8 +928,9 @@ int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
   LTR_LAUNCH_CHECK();
   const float* dz = c.ws.dy;
   if (proj) {
-    RC(gemm_tn(c, c.ws.dy, z, t->g(LTR_WT_PROJECT_OUT), N, De, H));
-    RC(gemm_nn(c, c.ws.dy, t->p(LTR_WT_PROJECT_OUT), nullptr, c.ws.dz, N, De, H));
+    float* sdy = grad_amax(c, c.ws.dy, (size_t)N * De);
+    RC(gemm_tn(c, c.ws.dy, z, t->g(LTR_WT_PROJECT_OUT), N, De, H, sdy));
+    RC(gemm_nn(c, c.ws.dy, t->p(LTR_WT_PROJECT_OUT), nullptr, c.ws.dz, N, De, H, sdy));
     dz = c.ws.dz;
   }
   const float* dhl = dz;
@@ -870,21 +961,23 @@ int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
       LTR_LAUNCH_CHECK();
       dmlp = c.ws.dsmall2;
     }
-    RC(gemm_tn(c, dmlp, L.f, G(LTR_WL_FC2_W), T, H, F));
+    float* s_dmlp = grad_amax(c, dmlp, (size_t)T * H);
+    RC(gemm_tn(c, dmlp, L.f, G(LTR_WL_FC2_W), T, H, F, s_dmlp));
     RC(colsum(c, dmlp, nullptr, T, H, G(LTR_WL_FC2_B)));
-    RC(gemm_nn(c, dmlp, P(LTR_WL_FC2_W), nullptr, c.ws.dbig, T, H, F));            // df [T, F]
+    RC(gemm_nn(c, dmlp, P(LTR_WL_FC2_W), nullptr, c.ws.dbig, T, H, F, s_dmlp));   // df [T, F]
     relu_bwd_kernel<<<1024, 256, 0, s>>>(c.ws.dbig, L.f, (size_t)T * F);
     LTR_LAUNCH_CHECK();
-    RC(gemm_tn(c, c.ws.dbig, mlp_in, G(LTR_WL_FC1_W), T, F, H));
+    float* s_df = grad_amax(c, c.ws.dbig, (size_t)T * F);
+    RC(gemm_tn(c, c.ws.dbig, mlp_in, G(LTR_WL_FC1_W), T, F, H, s_df));
     RC(colsum(c, c.ws.dbig, nullptr, T, F, G(LTR_WL_FC1_B)));
     // ---- dmid = ds2 + d(mlp_in -> mid)
     float* dmid;
     if (d.pre_ln) {        // mlp_in = LN2(mid): dmid = ds2 + LN2_bwd(da2)
-      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_FC1_W), nullptr, c.ws.dsmall, T, F, H));   // da2 (pre-LN has not used dsmall so far)
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_FC1_W), nullptr, c.ws.dsmall, T, F, H, s_df));   // da2 (pre-LN has not used dsmall so far)
       RC(ln_bwd(c, L.mid, P(LTR_WL_LN2_W), c.ws.dsmall, ds2, T, H, dh, G(LTR_WL_LN2_W), G(LTR_WL_LN2_B)));
       dmid = dh;
     } else {               // mlp_in = mid
-      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_FC1_W), ds2, dh, T, F, H));
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_FC1_W), ds2, dh, T, F, H, s_df));
       dmid = dh;
     }
     // ---- attention half.  ds1 = gradient w.r.t. s1 = x0 + dropout(out_proj(ao))
@@ -899,10 +992,11 @@ int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
       LTR_LAUNCH_CHECK();
       dproj = c.ws.dsmall2;
     }
-    RC(gemm_tn(c, dproj, L.ao, G(LTR_WL_OUT_W), T, H, H));
+    float* s_dproj = grad_amax(c, dproj, (size_t)T * H);
+    RC(gemm_tn(c, dproj, L.ao, G(LTR_WL_OUT_W), T, H, H, s_dproj));
     RC(colsum(c, dproj, nullptr, T, H, G(LTR_WL_OUT_B)));
     float* dao = c.ws.xhd;                                                           // free between LN backward calls
-    RC(gemm_nn(c, dproj, P(LTR_WL_OUT_W), nullptr, dao, T, H, H));
+    RC(gemm_nn(c, dproj, P(LTR_WL_OUT_W), nullptr, dao, T, H, H, s_dproj));
     {
       dim3 grid(T / BQ + N, d.num_heads);
       attn_bwd_dq_kernel<<<grid, 64 * BW, 0, s>>>(L.qkv, L.ao, dao, L.lse, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig, c.ws.Dq);
@@ -910,21 +1004,23 @@ int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
       attn_bwd_dkv_kernel<<<grid, 64 * BW, 0, s>>>(L.qkv, dao, L.lse, c.ws.Dq, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig);
       LTR_LAUNCH_CHECK();
     }
-    RC(gemm_tn(c, c.ws.dbig, qkv_in, G(LTR_WL_QKV_W), T, 3 * H, H));
+    float* s_dqkv = grad_amax(c, c.ws.dbig, (size_t)T * 3 * H);
+    RC(gemm_tn(c, c.ws.dbig, qkv_in, G(LTR_WL_QKV_W), T, 3 * H, H, s_dqkv));
     RC(colsum(c, c.ws.dbig, nullptr, T, 3 * H, G(LTR_WL_QKV_B)));
     if (d.pre_ln) {        // qkv_in = LN1(x0): dx0 = ds1 + LN1_bwd
       float* da1 = c.ws.dsmall2;
-      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_QKV_W), nullptr, da1, T, 3 * H, H));
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_QKV_W), nullptr, da1, T, 3 * H, H, s_dqkv));
       RC(ln_bwd(c, L.x0, P(LTR_WL_LN1_W), da1, ds1, T, H, dh, G(LTR_WL_LN1_W), G(LTR_WL_LN1_B)));
     } else {               // qkv_in = x0
-      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_QKV_W), ds1, dh, T, 3 * H, H));
+      RC(gemm_nn(c, c.ws.dbig, P(LTR_WL_QKV_W), ds1, dh, T, 3 * H, H, s_dqkv));
     }
   }
   // embedding: h0 = project_in(tok) + pos
   const float* dtok = dh;
   if (proj) {
-    RC(gemm_tn(c, dh, c.ws.tok, t->g(LTR_WT_PROJECT_IN), T, H, De));
-    RC(gemm_nn(c, dh, t->p(LTR_WT_PROJECT_IN), nullptr, c.ws.dsmall, T, H, De));
+    float* s_dh = grad_amax(c, dh, (size_t)T * H);
+    RC(gemm_tn(c, dh, c.ws.tok, t->g(LTR_WT_PROJECT_IN), T, H, De, s_dh));
+    RC(gemm_nn(c, dh, t->p(LTR_WT_PROJECT_IN), nullptr, c.ws.dsmall, T, H, De, s_dh));
     dtok = c.ws.dsmall;
   }
   embed_bwd_kernel<<<T, 256, 0, s>>>(ids, cu, N, T, dh, dtok, H, De, d.vocab_size, d.pos_rows, t->g(LTR_WT_EMBED_POS),
