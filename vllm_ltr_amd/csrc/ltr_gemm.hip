@@ -82,7 +82,14 @@ struct Epilogue {
   const float* r_gamma;   // [N]
   const float* r_beta;    // [N]
   int r_parts;
+  const float* osc_a;     // LNS: max|x| of the operands' source tensors (the product is divided by their split scales)
+  const float* osc_b;
 };
+
+// LNS rides on the consumer arithmetic v = (acc - mean c_n) rstd with mean = 0, c_n = 0, rstd = the output scale
+__device__ __forceinline__ float2 out_scale_stat(const Epilogue& ep) {
+  return make_float2(0.f, 1.f / (split_scale(*ep.osc_a) * split_scale(*ep.osc_b)));
+}
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 template <bool SPLIT>
@@ -190,7 +197,7 @@ __device__ unsigned long long g_waits[8192 * 2];
 // the exact fp16 checkpoint values (gamma rides on the ACTIVATION side, where the hi|lo split absorbs it); the
 // power-of-two scale keeps lo = a' - hi out of the fp16 subnormals for residual streams of magnitude ~0.01.
 constexpr float LN_FOLD_SCALE = 16.f;
-enum { LN_NONE = 0, LNP = 1, LNC = 2 };
+enum { LN_NONE = 0, LNP = 1, LNC = 2, LNS = 3 };   // LNS: plain epilogue on acc * out_scale (GemmArgs::osc_a / osc_b)
 
 // (mean, M2) of the 64-column pieces of one row -> (mean, rstd * out_scale).  Shifted-data sums around the first piece's
 // mean (equal counts per piece): the loads of all pieces are independent of each other and fly together (a serial Chan
@@ -246,8 +253,8 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
       rb.z = (rb.z - rst.x) * rst.y * g.z + b.z; rb.w = (rb.w - rst.x) * rst.y * g.w + b.w;
     }
   }
-  if (LNM == LNC) {   // v = (acc - mean c_n) rstd / scale (+ d_n, held in bias)
-    static_assert(!(LNM == LNC && RLN), "consumer epilogue and LayerNorm'd residual never meet");
+  if (LNM == LNC || LNM == LNS) {   // v = (acc - mean c_n) rstd / scale (+ d_n, held in bias)
+    static_assert(!((LNM == LNC || LNM == LNS) && RLN), "consumer epilogue and LayerNorm'd residual never meet");
     va.x = (va.x - st2.x * lnv_a.x) * st2.y; va.y = (va.y - st2.x * lnv_a.y) * st2.y;
     va.z = (va.z - st2.x * lnv_a.z) * st2.y; va.w = (va.w - st2.x * lnv_a.w) * st2.y;
     vb.x = (vb.x - st2.x * lnv_b.x) * st2.y; vb.y = (vb.y - st2.x * lnv_b.y) * st2.y;
@@ -451,7 +458,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
   }
   float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;      // LNP: gamma * scale; LNC: c_n
-  if (LNM != LN_NONE && !RLN && ccol < N) {                            // (RLN instances fetch it in their second sweep)
+  if ((LNM == LNP || LNM == LNC) && !RLN && ccol < N) {                // (RLN instances fetch it in their second sweep)
     const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
     lnv_a = *reinterpret_cast<const float4*>(src + ccol);
     lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
@@ -560,6 +567,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         if (!ok[it]) continue;
         float2 st2 = make_float2(0.f, 0.f);
         if (LNM == LNC || RLN) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
+        if (LNM == LNS) st2 = out_scale_stat(ep);
         epilogue_piece<LNM, RLN>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, st2, gr[it], ccol,
                                  ccol_b, o[it], M, lane, tn * 4 + wc);
       }
@@ -791,7 +799,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
         bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
       }
       float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;    // LNP: gamma * scale; LNC: c_n
-      if (LNM != LN_NONE) {
+      if (LNM == LNP || LNM == LNC) {
         const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
         lnv_a = *reinterpret_cast<const float4*>(src + ccol);
         lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
@@ -802,6 +810,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
       }
       float2 st2 = make_float2(0.f, 0.f);
       if (LNM == LNC || RLN) st2 = s_stat[srow];
+      if (LNM == LNS) st2 = out_scale_stat(ep);
       epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
                                tn * P64 + pc);
     }
@@ -969,8 +978,12 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
-              g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts};
-  const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : LN_NONE);
+              g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts, g.osc_a, g.osc_b};
+  const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : (g.osc_a ? LNS : LN_NONE));
+  if (g.osc_a && (wdtype != LTR_W_F16 || !g.osc_b || g.ln_gamma || g.ln_stats_in || g.rln_stats)) {
+    set_error("gemm: scaled operands (osc_a / osc_b) need F16 mode, both scales and no LayerNorm fold");
+    return LTR_E_INVAL;
+  }
   const bool rln = g.rln_stats != nullptr;
   if (rln && (wdtype != LTR_W_F16 || lnm == LNC || g.relu || !g.resid || !g.rln_gamma || !g.rln_beta || g.rln_parts * 64 != g.N ||
               g.rln_stats == g.ln_stats_out)) {
@@ -1043,6 +1056,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     if (rln) { if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, true, __VA_ARGS__); else LTR_SMALL_LAUNCH(LN_NONE, true, __VA_ARGS__); } \
     else if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, false, __VA_ARGS__);                                                        \
     else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, false, __VA_ARGS__);                                                        \
+    else if (lnm == LNS) LTR_SMALL_LAUNCH(LNS, false, __VA_ARGS__);                                                        \
     else LTR_SMALL_LAUNCH(LN_NONE, false, __VA_ARGS__);                                                                    \
   } while (0)
         // (a ring of eight stages for grids of at most one workgroup per CU was measured and is slower: fc2 of a
@@ -1061,6 +1075,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     if (rln) { if (lnm == LNP) LTR_BIG_LAUNCH(LNP, true); else LTR_BIG_LAUNCH(LN_NONE, true); }
     else if (lnm == LNP) LTR_BIG_LAUNCH(LNP, false);
     else if (lnm == LNC) LTR_BIG_LAUNCH(LNC, false);
+    else if (lnm == LNS) LTR_BIG_LAUNCH(LNS, false);
     else LTR_BIG_LAUNCH(LN_NONE, false);
 #undef LTR_BIG_LAUNCH
   } else {

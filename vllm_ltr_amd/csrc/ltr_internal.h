@@ -76,6 +76,11 @@ struct GemmArgs {
   const float* rln_gamma = nullptr;  // [N]
   const float* rln_beta = nullptr;   // [N]
   int rln_parts = 0;                 // N / 64
+  // Scaled operands (the training step's split x split GEMMs, ltr_trainer.hip): the product is multiplied by
+  // 1 / (split_scale(*osc_a) * split_scale(*osc_b)) - exact powers of two - before bias / ReLU / residual.  F16 mode,
+  // not together with the LayerNorm fold.
+  const float* osc_a = nullptr;      // device: max|x| of the A operand's source tensor
+  const float* osc_b = nullptr;      // device: max|x| of the B operand's source tensor
 };
 
 // launchers (each in its own .hip file)
@@ -173,6 +178,13 @@ __device__ __forceinline__ size_t slab_off(int row, int col, int ld) {
   return ((size_t)(col >> 5) * ld + row) * 32 + (col & 31);
 }
 
+// Power-of-two scale that brings a tensor of magnitude amax to ~2^12 before it is split into fp16 hi + lo (training:
+// gradients are 1e-3 ... 1e-9 in magnitude, far below fp16's normal range (6e-5), where hi would be a subnormal and lo
+// flush to zero - the split would silently degrade to a few bits).  Scaling by 2^k is exact and is undone exactly in
+// the GEMM epilogue (GemmArgs::osc_a / osc_b).  Elements down to 2^-15 of the tensor's maximum keep all 22 bits.
+__device__ __forceinline__ float split_scale(float amax) {
+  return amax > 0.f && amax < INFINITY ? ldexpf(1.f, 12 - ilogbf(amax)) : 1.f;
+}
 __device__ __forceinline__ void split_f16(float a, __half& hi, __half& lo) {
   asm volatile("" : "+v"(a));
   hi = __float2half_rn(a);

@@ -56,15 +56,22 @@ __global__ void __launch_bounds__(256) transpose_pad_kernel(const float* __restr
   }
 }
 
-// max |x| of a tensor into *slot (non-negative floats order like their bit patterns; the slot is zeroed per step)
+// max |x| of a tensor into *slot (non-negative floats order like their bit patterns; the slot is zeroed per step).
+// At most 128 workgroups: every workgroup ends in one atomic on the same address, and those serialise at the L2 -
+// 740 of them made this kernel 14.7 us for a 12 MB tensor that streams in 2.
+constexpr int AMAX_BLOCKS = 128;
 __global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ slot) {
-  float m = 0.f;
-  const size_t n4 = n / 4;
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  auto mx = [](float m, const float4 v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {       // four independent loads in flight per thread
+    const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    m0 = mx(m0, a); m1 = mx(m1, b); m2 = mx(m2, c); m3 = mx(m3, d);
   }
+  for (; i < n4; i += stride) m0 = mx(m0, x4[i]);
+  float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
   m = wave_max(m);
   __shared__ float sm[4];
@@ -75,14 +82,6 @@ __global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, 
     if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
   }
 }
-// Power-of-two scale that brings a tensor of magnitude amax to ~2^12 before it is split into fp16 hi + lo: gradients
-// are 1e-3 ... 1e-9 in magnitude, far below fp16's normal range (6e-5), where hi would be a subnormal and lo flush to
-// zero - the split would silently degrade to a few bits.  Scaling by 2^k is exact and is undone (exactly) by
-// gemm_finish_kernel.  Elements down to 2^-15 of the tensor's maximum keep all 22 bits.
-__device__ __forceinline__ float split_scale(float amax) {
-  return amax > 0.f && amax < INFINITY ? ldexpf(1.f, 12 - ilogbf(amax)) : 1.f;
-}
-
 // f32 B [N, K] -> the split-fp16 GEMM's slab-major weight image of [Bh | Bl] ([N, 2K] with hi(B) in the first K
 // columns and lo(B) = fp16(B - hi) in the last K): element (n, k') at ((k' >> 5) * N + n) * 32 + (k' & 31).  One 16-byte
 // piece (8 halves) per thread.
@@ -167,38 +166,6 @@ __global__ void __launch_bounds__(256) split_T_kernel(const float* __restrict__ 
   } else {
     *reinterpret_cast<uint4*>(dst + piece) = *reinterpret_cast<const uint4*>(h);
     *reinterpret_cast<uint4*>(dst + second + piece) = *reinterpret_cast<const uint4*>(l);
-  }
-}
-
-// out = (ReLU)(raw / (sa sb) + bias) + resid: undoes the operand scales of the split GEMM (exact powers of two) and
-// applies what the f32 GEMM's epilogue applies; optionally also writes the result as row-major hi | lo planes (QKV for
-// the MFMA attention).  8 consecutive columns per thread.
-__global__ void __launch_bounds__(256) gemm_finish_kernel(const float* __restrict__ raw, const float* __restrict__ amax_a,
-                                                          const float* __restrict__ amax_b, const float* __restrict__ bias, const float* resid, float* out,
-                                                          size_t n8, int N, int relu, __half* __restrict__ p_hi,
-                                                          __half* __restrict__ p_lo) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n8) return;
-  const float inv = 1.f / (split_scale(*amax_a) * split_scale(*amax_b));
-  const int col = (int)((i * 8) % N);
-  float v[8];
-  *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(raw + i * 8);
-  *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(raw + i * 8 + 4);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float x = v[e] * inv + (bias ? bias[col + e] : 0.f);
-    if (relu) x = fmaxf(x, 0.f);
-    if (resid) x += resid[i * 8 + e];
-    v[e] = x;
-  }
-  *reinterpret_cast<float4*>(out + i * 8) = *reinterpret_cast<const float4*>(v);
-  *reinterpret_cast<float4*>(out + i * 8 + 4) = *reinterpret_cast<const float4*>(v + 4);
-  if (p_hi) {
-    __half h[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) split_f16(v[e], h[e], l[e]);
-    *reinterpret_cast<uint4*>(p_hi + i * 8) = *reinterpret_cast<const uint4*>(h);
-    *reinterpret_cast<uint4*>(p_lo + i * 8) = *reinterpret_cast<const uint4*>(l);
   }
 }
 
@@ -654,7 +621,7 @@ struct TrainWs {
   float *dh, *dbig, *dsmall, *dsmall2, *xhd, *t1, *t2, *partial, *Dq;
   float *opa, *wb;         // split-fp16 GEMM operands of one call: A image hi|lo over 2K, [Bh | Bl] weight image
   float *qkvp, *aop;       // hi | lo planes of qkv [2][T, 3H] and of the attention output [2][T, H] (fp16 path)
-  float *gtmp, *scales;    // raw (scaled) product of a split GEMM; max |x| of the operands of every GEMM of the step
+  float* scales;           // max |x| slots of the GEMM operands of the step
   int32_t* blk;
   int32_t* blk2;     // work list of the MFMA attention forward (fp16 path)
   size_t bytes;
@@ -680,7 +647,7 @@ TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, b
   w.dh = take(T * H); w.dbig = take(T * big); w.dsmall = take(T * H); w.dsmall2 = take(T * H); w.xhd = take(T * H);
   w.t1 = take(big * Tp); w.t2 = take(big * Tp);
   w.qkvp = take(T * 3 * H + 64); w.aop = take(T * H + 64);           // 2 planes x 2 B = one float per element
-  w.gtmp = take(std::max(big * Tp, F * H) + 64); w.scales = take(MAX_GEMMS * 2);
+  w.scales = take(MAX_GEMMS * 2);
   w.opa = take(2 * big * Tp + 64);                                   // 2 planes x M x 2K halves = 2 M K floats
   w.wb = take(std::max(std::max(big * Tp, big * H), F * H) + 64);    // N x 2K halves = N K floats
   w.partial = take(((size_t)(T + CS_ROWS - 1) / CS_ROWS + 1) * big);
@@ -711,7 +678,7 @@ float* amax_of(Ctx& c, const float* p, size_t n, bool stable) {
   }
   if (c.n_slot >= 2 * MAX_GEMMS) { set_error("ltr_train_step: more than %d GEMM operands in one step", 2 * MAX_GEMMS); return nullptr; }
   float* sl = c.ws.scales + c.n_slot++;
-  amax_kernel<<<(unsigned)std::min<size_t>((n + 4095) / 4096, 2048), 256, 0, c.s>>>(p, n, sl);
+  amax_kernel<<<(unsigned)std::min<size_t>((n + 4095) / 4096, AMAX_BLOCKS), 256, 0, c.s>>>(p, n, sl);
   if (stable) c.amax_cache[p] = sl;
   return sl;
 }
@@ -729,7 +696,7 @@ int transpose_pad(const float* in, int R, int C, int Rp, float* out, hipStream_t
 
 // C[M, N] = A B^T (+ bias)(ReLU)(+ resid) with A = a (M x K), B = b (N x K), f32 in memory, on the split-fp16 MFMA kernel:
 // [A | A] [Bh | Bl]^T over K' = 2K (Ah Bh + Al Bh + Ah Bl + Al Bl), each operand scaled into fp16's range by a power of
-// two first (split_scale), undone by gemm_finish_kernel.  Per operand ONE preparation kernel (transposing or not).
+// two first (split_scale), undone in the GEMM epilogue (GemmArgs::osc_a / osc_b).  Per operand ONE preparation kernel (transposing or not).
 bool split_ok(const Ctx& c, const Opnd& a, const Opnd& b) {
   if (c.t->use_f32 || b.rows % 64) return false;
   if (a.trans && a.rows % 64) return false;
@@ -758,16 +725,14 @@ int gemm_split(Ctx& c, Opnd a, Opnd b, const float* bias, const float* resid, fl
     split_pack_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, s>>>(b.p, reinterpret_cast<__half*>(c.ws.wb), N, K, b.amax);
   }
   LTR_LAUNCH_CHECK();
+  // the product comes back scaled by both operand scales: the GEMM epilogue divides them out (exact powers of two)
+  // before bias / ReLU / residual, and writes the row-major hi | lo planes of the result when asked (QKV for the MFMA attention)
   GemmArgs r{};
-  r.a = AOp{ah, al}; r.w = c.ws.wb; r.out_f32 = c.ws.gtmp; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
-  int rc = launch_gemm(LTR_W_F16, r, s);
-  if (rc) return rc;
-  const size_t n8 = (size_t)M * N / 8;
-  gemm_finish_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, a.amax, b.amax, bias, resid, out, n8, N, relu,
-                                                                 planes ? (__half*)planes->hi : nullptr,
-                                                                 planes ? (__half*)planes->lo : nullptr);
-  LTR_LAUNCH_CHECK();
-  return LTR_OK;
+  r.a = AOp{ah, al}; r.w = c.ws.wb; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
+  r.bias = bias; r.resid = resid; r.out_f32 = out; r.relu = relu;
+  if (planes) r.out_split = *planes;
+  r.osc_a = a.amax; r.osc_b = b.amax;
+  return launch_gemm(LTR_W_F16, r, s);
 }
 
 // C[M, N] = A[M, K] B[N, K]^T (+ bias)(ReLU)(+ resid), all f32 in memory.  Forward operands: both stable for the step.
