@@ -533,6 +533,316 @@ __global__ void __launch_bounds__(LQ_WAVES * 64) attn_lastq_kernel(const float* 
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Training: attention BACKWARD on the forward kernel's machinery (the reference gets it from autograd
+// through vllm's attention replaced by HF's eager attention in train/trainer.py).  Forward: S2 = (q k) scale log2e,
+// P = exp2(S2 - lse2), O = P V.  With D_q = sum_d dO O:
+//     dV = P^T dO          dP = dO V^T          dS = P (dP - D_q)          dQ = scale dS K          dK = scale dS^T Q
+// Two kernels over the forward's work list of 128-row blocks; both keep one side's fragments in registers and stream
+// 32-row tiles of the other side through a 3-stage LDS ring exactly like the forward (global_load_lds, counted vmcnt):
+//   dq  kernel: block = 128 queries; resident B fragments Q, dO; streamed K (twice: row layout for S^T = K Q^T and
+//               transpose-read layout for dQ^T += K^T dS^T) and V (row layout for dP^T = V dO^T).
+//   dkv kernel: block = 128 keys; resident B fragments K, V; streamed Q and dO, each in both layouts:
+//               S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+// In both, the accumulator registers of the "score" products are, converted to fp16 hi | lo, directly the B operand of
+// the accumulating products (the forward's P trick), and the transposed A operands come from ds_read_b64_tr_b16.
+// Every product is three split passes (lo hi + hi lo + hi hi), f32 accumulate.  dO arrives scaled by a power of two
+// s_O (gradients are far below fp16's range) chosen from max|dO| and max|qkv| so that |dP|, |D| <= 2^14 and |dS| <= 2^15
+// stay inside fp16; everything downstream is linear in dO and the outputs are divided by s_O again (exact).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float attn_bwd_scale(float amax_do, float amax_qkv) {
+  if (!(amax_do > 0.f) || !(amax_do < INFINITY)) return 1.f;
+  const int eq = (amax_qkv > 0.f && amax_qkv < INFINITY) ? ilogbf(amax_qkv) + 1 : 0;
+  return ldexpf(1.f, 14 - 6 - (ilogbf(amax_do) + 1) - max(eq, 0));
+}
+
+// 32 x 32 product block: rows = the 32 rows of an LDS tile in the row layout (k_off), columns = the resident fragments
+__device__ __forceinline__ f32x16 bwd_score(const __half* __restrict__ s_hi, const __half* __restrict__ s_lo,
+                                            const f16x8 (&bh)[4], const f16x8 (&bl)[4], int lq, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = 2 * ks + lh;
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(s_hi + k_off(lq, c));
+    const f16x8 al = *reinterpret_cast<const f16x8*>(s_lo + k_off(lq, c));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// the 16 accumulator values of a lane (its column, 16 of the 32 tile rows) -> fp16 hi | lo B fragments of the two k-steps
+__device__ __forceinline__ void bwd_split(const f32x16& x, f16x8& h0, f16x8& h1, f16x8& l0, f16x8& l1) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 a = (_Float16)x[i], b = (_Float16)x[8 + i];
+    h0[i] = a; h1[i] = b;
+    l0[i] = (_Float16)(x[i] - (float)a);
+    l1[i] = (_Float16)(x[8 + i] - (float)b);
+  }
+}
+// o[dt] (rows = d, cols = the lane's column) += T^T X with T the 32 x 64 LDS tile in the transpose-read layout (v_off) and
+// X the split accumulator fragments (tile rows in accumulator register order) - the forward's O^T += V^T P^T
+__device__ __forceinline__ void bwd_accum_T(f32x16 (&o)[2], const __half* __restrict__ t_hi, const __half* __restrict__ t_lo,
+                                            const f16x8& h0, const f16x8& h1, const f16x8& l0, const f16x8& l1, int lane, int lh) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f16x8 th, tl;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int row = 16 * g + 8 * hf + 4 * lh + ((lane & 15) >> 2);
+        const int off = v_off(row, dt * 32 + (lane & 16) + (lane & 3) * 4);
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t_hi + off));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t_lo + off));
+        const f16x4 ah = __builtin_bit_cast(f16x4, a), bl = __builtin_bit_cast(f16x4, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { th[4 * hf + e] = ah[e]; tl[4 * hf + e] = bl[e]; }
+      }
+      const f16x8 xh = g ? h1 : h0, xl = g ? l1 : l0;
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, xh, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, xl, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, xh, o[dt], 0, 0, 0);
+    }
+  }
+}
+// accumulator (rows d = dt * 32 + 8 j + 4 lh + i, column = this lane's row of the block) -> f32 row of dqkv
+__device__ __forceinline__ void bwd_store(const f32x16 (&o)[2], float f, float* __restrict__ dst /*row + column base*/, int lh) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(dst + dt * 32 + 8 * j + 4 * lh) =
+          make_float4(o[dt][4 * j] * f, o[dt][4 * j + 1] * f, o[dt][4 * j + 2] * f, o[dt][4 * j + 3] * f);
+}
+
+constexpr int BWD_DQ_PLANES = 6;    // K rows hi|lo, K transposable hi|lo, V rows hi|lo
+constexpr int BWD_DKV_PLANES = 8;   // Q rows hi|lo, Q transposable hi|lo, dO rows hi|lo, dO transposable hi|lo
+constexpr int BWD_STAT_H = 4 * 128; // halves: per wave 64 floats (lse2 | D of the tile's 32 queries), dkv kernel
+
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_f16s_kernel(
+    const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const __half* __restrict__ do_hi,
+    const __half* __restrict__ do_lo, const float* __restrict__ lse2, const float* __restrict__ Dq,
+    const float* __restrict__ amax_do, const float* __restrict__ amax_qkv, const int32_t* __restrict__ blk_start,
+    const int4* __restrict__ blk_desc, int n_req, int H, float scale, float* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) __half smem[];
+  constexpr int STAGE_H = BWD_DQ_PLANES * PLANE_H;
+  const int b = blockIdx.x;
+  if (b >= blk_start[n_req]) return;
+  const int head = blockIdx.y, nh = H / D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int4 desc = blk_desc[b];
+  const int qblk0 = desc.y, t0 = desc.z, L = desc.w;
+  const int q0 = qblk0 + wave * 32;
+  const bool wave_active = q0 < L;
+  const size_t ld = (size_t)3 * H;
+  const int lq = lane & 31, lh = lane >> 5;
+  const float s_o = attn_bwd_scale(*amax_do, *amax_qkv);
+  const float sl2e = scale * 1.4426950408889634f;
+
+  f16x8 qh[4], ql[4], doh[4], dol[4];
+  float lse, dsum;
+  {
+    const size_t row = (size_t)(t0 + min(q0 + lq, L - 1));
+    const size_t qo = row * ld + head * D + 8 * lh, oo = row * H + head * D + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *reinterpret_cast<const f16x8*>(qkv_hi + qo + ks * 16);
+      ql[ks] = *reinterpret_cast<const f16x8*>(qkv_lo + qo + ks * 16);
+      doh[ks] = *reinterpret_cast<const f16x8*>(do_hi + oo + ks * 16);
+      dol[ks] = *reinterpret_cast<const f16x8*>(do_lo + oo + ks * 16);
+    }
+    lse = lse2[row * nh + head];
+    dsum = Dq[row * nh + head] * s_o;
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kc_log = (lane & 7) ^ ((lrow >> 1) & 7);
+  const int vc = (lane & 7) ^ (((lrow >> 1) & 1) * LTR_ATTN_VSWZ);
+  auto issue = [&](int stage, int kt) {
+    const size_t rowoff = (size_t)(t0 + min(kt + lrow, L - 1)) * ld + head * D;
+    __half* base = smem + stage * STAGE_H + wave * 8 * D;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc_log * 8), (lds_void*)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + vc * 8), (lds_void*)(base + 2 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + kc_log * 8), (lds_void*)(base + 4 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + kc_log * 8), (lds_void*)(base + 5 * PLANE_H), 16, 0, 0);
+  };
+  const int kend = min(L, qblk0 + 128);
+  const int ntile = (kend + TK - 1) / TK;
+  issue(0, 0);
+  if (ntile > 1) issue(1, TK);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qh[ks]), "v"(ql[ks]), "v"(doh[ks]), "v"(dol[ks]));
+  asm volatile("" ::"v"(lse), "v"(dsum));
+  for (int it = 0; it < ntile; ++it) {
+    const int kt = it * TK;
+    if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < ntile) issue((it + 2) % NSTAGE, kt + 2 * TK);
+    if (!wave_active || kt > q0) continue;
+    const __half* st = smem + (it % NSTAGE) * STAGE_H;
+    f32x16 sacc = bwd_score(st, st + PLANE_H, qh, ql, lq, lh);                        // S^T  = K Q^T
+    const f32x16 dpacc = bwd_score(st + 4 * PLANE_H, st + 5 * PLANE_H, doh, dol, lq, lh);   // dP^T = V dO^T  (x s_O)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kr = (i & 3) + 8 * (i >> 2) + 4 * lh;                                 // key row inside the tile
+      const float p = (kt == q0 && kr > lq) ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[i], sl2e, -lse));
+      sacc[i] = p * (dpacc[i] - dsum);                                                // dS^T (x s_O)
+    }
+    f16x8 h0, h1, l0, l1;
+    bwd_split(sacc, h0, h1, l0, l1);
+    bwd_accum_T(o, st + 2 * PLANE_H, st + 3 * PLANE_H, h0, h1, l0, l1, lane, lh);     // dQ^T += K^T dS^T
+  }
+  if (!wave_active || q0 + lq >= L) return;
+  bwd_store(o, scale / s_o, dqkv + (size_t)(t0 + q0 + lq) * ld + head * D, lh);
+}
+
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_f16s_kernel(
+    const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const __half* __restrict__ do_hi,
+    const __half* __restrict__ do_lo, const float* __restrict__ lse2, const float* __restrict__ Dq,
+    const float* __restrict__ amax_do, const float* __restrict__ amax_qkv, const int32_t* __restrict__ blk_start,
+    const int4* __restrict__ blk_desc, int n_req, int H, float scale, float* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) __half smem[];
+  constexpr int STAGE_H = BWD_DKV_PLANES * PLANE_H + BWD_STAT_H;
+  const int b = blockIdx.x;
+  if (b >= blk_start[n_req]) return;
+  const int head = blockIdx.y, nh = H / D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int4 desc = blk_desc[b];
+  const int kblk0 = desc.y, t0 = desc.z, L = desc.w;
+  const int k0 = kblk0 + wave * 32;
+  const bool wave_active = k0 < L;
+  const size_t ld = (size_t)3 * H;
+  const int lq = lane & 31, lh = lane >> 5;
+  const float s_o = attn_bwd_scale(*amax_do, *amax_qkv);
+  const float sl2e = scale * 1.4426950408889634f;
+
+  f16x8 kh[4], kl[4], vh[4], vl[4];
+  {
+    const size_t ko = (size_t)(t0 + min(k0 + lq, L - 1)) * ld + H + head * D + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kh[ks] = *reinterpret_cast<const f16x8*>(qkv_hi + ko + ks * 16);
+      kl[ks] = *reinterpret_cast<const f16x8*>(qkv_lo + ko + ks * 16);
+      vh[ks] = *reinterpret_cast<const f16x8*>(qkv_hi + ko + H + ks * 16);
+      vl[ks] = *reinterpret_cast<const f16x8*>(qkv_lo + ko + H + ks * 16);
+    }
+  }
+  f32x16 ov[2], ok[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ov[0][i] = 0.f; ov[1][i] = 0.f; ok[0][i] = 0.f; ok[1][i] = 0.f; }
+
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kc_log = (lane & 7) ^ ((lrow >> 1) & 7);
+  const int vc = (lane & 7) ^ (((lrow >> 1) & 1) * LTR_ATTN_VSWZ);
+  auto issue = [&](int stage, int qt) {
+    const size_t row = (size_t)(t0 + min(qt + lrow, L - 1));
+    const size_t qo = row * ld + head * D, oo = row * H + head * D;
+    __half* base = smem + stage * STAGE_H + wave * 8 * D;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + qo + kc_log * 8), (lds_void*)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + qo + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + qo + vc * 8), (lds_void*)(base + 2 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + qo + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(do_hi + oo + kc_log * 8), (lds_void*)(base + 4 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(do_lo + oo + kc_log * 8), (lds_void*)(base + 5 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(do_hi + oo + vc * 8), (lds_void*)(base + 6 * PLANE_H), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(do_lo + oo + vc * 8), (lds_void*)(base + 7 * PLANE_H), 16, 0, 0);
+    // the tile's 32 (lse2, D) pairs, one private copy per wave (4 bytes per lane: lanes 0-31 lse2, 32-63 D)
+    const size_t srow = (size_t)(t0 + min(qt + lq, L - 1)) * nh + head;
+    float* sbase = reinterpret_cast<float*>(smem + stage * STAGE_H + BWD_DKV_PLANES * PLANE_H) + wave * 64;
+    __builtin_amdgcn_global_load_lds((gbl_void*)((lh ? Dq : lse2) + srow), (lds_void*)(sbase), 4, 0, 0);
+  };
+  // queries that see this block's keys: [kblk0, L), in tiles of 32 (kblk0 is a multiple of 128)
+  const int ntile = (L - kblk0 + TK - 1) / TK;
+  issue(0, kblk0);
+  if (ntile > 1) issue(1, kblk0 + TK);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(kh[ks]), "v"(kl[ks]), "v"(vh[ks]), "v"(vl[ks]));
+  for (int it = 0; it < ntile; ++it) {
+    const int qt = kblk0 + it * TK;
+    if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < ntile) issue((it + 2) % NSTAGE, qt + 2 * TK);
+    if (!wave_active || qt + TK - 1 < k0) continue;            // every query of the tile precedes this wave's keys
+    const __half* st = smem + (it % NSTAGE) * STAGE_H;
+    const float* s_stat = reinterpret_cast<const float*>(st + BWD_DKV_PLANES * PLANE_H) + wave * 64;
+    f32x16 sacc = bwd_score(st, st + PLANE_H, kh, kl, lq, lh);                          // S  = Q K^T   (rows = queries)
+    f32x16 dpacc = bwd_score(st + 4 * PLANE_H, st + 5 * PLANE_H, vh, vl, lq, lh);       // dP = dO V^T  (x s_O)
+    const int key = k0 + lq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 ls = *reinterpret_cast<const float4*>(s_stat + 8 * j + 4 * lh);
+      const float4 dd = *reinterpret_cast<const float4*>(s_stat + 32 + 8 * j + 4 * lh);
+      const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * j + e;
+        const int q = qt + 8 * j + 4 * lh + e;
+        const float p = (q < key || q >= L) ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[i], sl2e, -lsv[e]));
+        sacc[i] = p;                                                                     // P
+        dpacc[i] = p * (dpacc[i] - ddv[e] * s_o);                                        // dS (x s_O)
+      }
+    }
+    f16x8 h0, h1, l0, l1;
+    bwd_split(sacc, h0, h1, l0, l1);
+    bwd_accum_T(ov, st + 6 * PLANE_H, st + 7 * PLANE_H, h0, h1, l0, l1, lane, lh);      // dV^T += dO^T P
+    bwd_split(dpacc, h0, h1, l0, l1);
+    bwd_accum_T(ok, st + 2 * PLANE_H, st + 3 * PLANE_H, h0, h1, l0, l1, lane, lh);      // dK^T += Q^T dS
+  }
+  if (!wave_active || k0 + lq >= L) return;
+  float* dst = dqkv + (size_t)(t0 + k0 + lq) * ld + head * D;
+  bwd_store(ok, scale / s_o, dst + H, lh);
+  bwd_store(ov, 1.f / s_o, dst + 2 * H, lh);
+}
+
+// D_q = sum_d dO O per (token, head), f32 (one wave per token row: lanes over the H columns)
+__global__ void __launch_bounds__(256) attn_bwd_rowdot_kernel(const float* __restrict__ o, const float* __restrict__ dout,
+                                                              int T, int H, float* __restrict__ Dq) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, nh = H / D;
+  if (row >= T) return;
+  // 16 lanes x float4 cover one head (64 columns): four heads per wave pass
+  for (int h0 = 0; h0 < nh; h0 += 4) {
+    const int head = h0 + (lane >> 4);
+    float v = 0.f;
+    if (head < nh) {
+      const size_t off = (size_t)row * H + head * D + (lane & 15) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(o + off), b = *reinterpret_cast<const float4*>(dout + off);
+      v = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    if (head < nh && (lane & 15) == 0) Dq[(size_t)row * nh + head] = v;
+  }
+}
+
+// f32 [rows, cols] -> row-major fp16 hi | lo planes of x * s (s = 1, or the attention-backward scale of dO)
+__global__ void __launch_bounds__(256) attn_bwd_planes_kernel(const float* __restrict__ x, size_t n8, const float* __restrict__ amax_do,
+                                                              const float* __restrict__ amax_qkv, __half* __restrict__ hi,
+                                                              __half* __restrict__ lo) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float s = amax_do ? attn_bwd_scale(*amax_do, *amax_qkv) : 1.f;
+  const float4 a = *reinterpret_cast<const float4*>(x + i * 8), b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+  __half h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split_f16(v[e], h[e], l[e]);
+  *reinterpret_cast<uint4*>(hi + i * 8) = *reinterpret_cast<const uint4*>(h);
+  *reinterpret_cast<uint4*>(lo + i * 8) = *reinterpret_cast<const uint4*>(l);
+}
+
 }  // namespace
 
 // the work list of `qb`-query blocks alone (the training backward walks 64-query blocks whatever kernel ran the forward)
@@ -584,6 +894,41 @@ int launch_attention_lastq(const float* q, AOp kv, const int32_t* cu, int n_req,
   const float scale_log2e = 0.125f * 1.4426950408889634f;
   attn_lastq_kernel<<<dim3(n_req, n_heads), LQ_WAVES * 64, 0, s>>>(q, (const __half*)kv.hi, (const __half*)kv.lo, cu, H,
                                                                    scale_log2e, (__half*)out.hi, (__half*)out.lo);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
+// Attention backward of the training step (split-fp16 MFMA): dqkv [T, 3H] f32 from the saved qkv / attention output /
+// log-sum-exp rows and the output gradient dout [T, H].  qkv_planes / do_planes: scratch for the fp16 hi | lo planes
+// ([2][T, 3H] and [2][T, H] halves); amax_do / amax_qkv: device slots holding max|dout| and max|qkv|; blk_start: the
+// forward's work list of 128-row blocks (launch_attention with F16 mode built it).
+int launch_attention_bwd(const float* qkv, const float* o, const float* dout, const float* lse2, const float* amax_do,
+                         const float* amax_qkv, const int32_t* blk_start, int n_req, int T, int H, int n_heads, float scale,
+                         void* qkv_planes, void* do_planes, float* Dq, float* dqkv, hipStream_t s) {
+  if (n_req == 0 || T == 0) return LTR_OK;
+  if (H != n_heads * D) { set_error("attention backward: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
+  const int4* blk_desc = reinterpret_cast<const int4*>(blk_start + ((n_req + 1 + 3) & ~3));
+  __half* qh = (__half*)qkv_planes;
+  __half* ql = qh + (size_t)T * 3 * H;
+  __half* dh = (__half*)do_planes;
+  __half* dl = dh + (size_t)T * H;
+  const size_t nq8 = (size_t)T * 3 * H / 8, no8 = (size_t)T * H / 8;
+  attn_bwd_planes_kernel<<<(unsigned)((nq8 + 255) / 256), 256, 0, s>>>(qkv, nq8, nullptr, nullptr, qh, ql);
+  attn_bwd_planes_kernel<<<(unsigned)((no8 + 255) / 256), 256, 0, s>>>(dout, no8, amax_do, amax_qkv, dh, dl);
+  attn_bwd_rowdot_kernel<<<(T + 3) / 4, 256, 0, s>>>(o, dout, T, H, Dq);
+  LTR_LAUNCH_CHECK();
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute((const void*)attn_bwd_dkv_f16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(NSTAGE * (BWD_DKV_PLANES * PLANE_H + BWD_STAT_H) * sizeof(__half))) == hipSuccess &&
+           hipFuncSetAttribute((const void*)attn_bwd_dq_f16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(NSTAGE * BWD_DQ_PLANES * PLANE_H * sizeof(__half))) == hipSuccess;
+  }();
+  (void)attr_ok;
+  dim3 grid(T / 128 + n_req, n_heads);
+  attn_bwd_dq_f16s_kernel<<<grid, 256, NSTAGE * BWD_DQ_PLANES * PLANE_H * sizeof(__half), s>>>(
+      qh, ql, dh, dl, lse2, Dq, amax_do, amax_qkv, blk_start, blk_desc, n_req, H, scale, dqkv);
+  attn_bwd_dkv_f16s_kernel<<<grid, 256, NSTAGE * (BWD_DKV_PLANES * PLANE_H + BWD_STAT_H) * sizeof(__half), s>>>(
+      qh, ql, dh, dl, lse2, Dq, amax_do, amax_qkv, blk_start, blk_desc, n_req, H, scale, dqkv);
   LTR_LAUNCH_CHECK();
   return LTR_OK;
 }

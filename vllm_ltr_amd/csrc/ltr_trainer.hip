@@ -665,6 +665,7 @@ struct Ctx {
   int T, N;
   bool eval = false;      // predictor.model.eval() (trainer.py:171): no dropout, forward only
   int n_slot = 0;         // max|x| slots handed out so far in this step (ws.scales)
+  bool attn_mfma = false; // the forward ran the split-fp16 MFMA attention (128-row work list in ws.blk2): so does the backward
   // max|x| of tensors that do not change for the rest of the step (weights, saved activations), by address: the
   // backward meets every forward operand again (X of dW = dY^T X, W of dX = dY W) and reuses its slot
   std::unordered_map<const void*, float*> amax_cache;
@@ -819,6 +820,7 @@ int forward(Ctx& c, const int64_t* ids, const int32_t* cu) {
     RC(gemm_nt(c, qkv_in, t->p(t->li(l, LTR_WL_QKV_W)), t->p(t->li(l, LTR_WL_QKV_B)), nullptr, L.qkv, T, 3 * H, H, 0, &planes));
     static const bool f32_attn = [] { const char* e = getenv("LTR_TRAIN_F32_ATTN"); return e && e[0] == '1'; }();   // A/B
     if (planes.hi && !f32_attn) {
+      c.attn_mfma = true;
       __half* op = reinterpret_cast<__half*>(c.ws.aop);
       // (own work list: the MFMA kernel walks 128-query blocks, the backward kernels 64-query blocks from ws.blk)
       if (l == 0) RC(launch_attention_blocks(cu, N, 64, c.ws.blk, s));
@@ -962,7 +964,16 @@ int backward(Ctx& c, const int64_t* ids, const int32_t* cu) {
     RC(colsum(c, dproj, nullptr, T, H, G(LTR_WL_OUT_B)));
     float* dao = c.ws.xhd;                                                           // free between LN backward calls
     RC(gemm_nn(c, dproj, P(LTR_WL_OUT_W), nullptr, dao, T, H, H, s_dproj));
-    {
+    static const bool f32_attn_bwd = [] { const char* e = getenv("LTR_TRAIN_F32_ATTN"); return e && e[0] == '1'; }();   // A/B
+    if (c.attn_mfma && !f32_attn_bwd) {
+      // split-fp16 MFMA backward over the forward's 128-row work list (ws.blk2); dO is scaled into fp16's range from
+      // max|dO| and max|qkv| (ltr_attn.hip), both taken on the stream
+      float* s_dao = grad_amax(c, dao, (size_t)T * H);
+      float* s_qkv = amax_of(c, L.qkv, (size_t)T * 3 * H, true);
+      if (!s_dao || !s_qkv) return LTR_E_INVAL;
+      RC(launch_attention_bwd(L.qkv, L.ao, dao, L.lse, s_dao, s_qkv, c.ws.blk2, N, T, H, d.num_heads, scale, c.ws.qkvp, c.ws.aop,
+                              c.ws.Dq, c.ws.dbig, s));
+    } else {
       dim3 grid(T / BQ + N, d.num_heads);
       attn_bwd_dq_kernel<<<grid, 64 * BW, 0, s>>>(L.qkv, L.ao, dao, L.lse, c.ws.blk, blk_desc, N, H, scale, c.ws.dbig, c.ws.Dq);
       LTR_LAUNCH_CHECK();
