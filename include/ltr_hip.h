@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LTR_ABI_VERSION 3
+#define LTR_ABI_VERSION 4
 
 enum {
   LTR_OK = 0,
@@ -374,6 +374,16 @@ int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* 
  * dst (device, f32, `capacity` floats) on `stream`; *count_out = its element count (dst NULL: size query). */
 int ltr_train_read(ltr_train_handle h, int32_t index, int32_t what, float* dst, size_t capacity,
                    size_t* count_out, void* stream);
+
+/* The attention block of the training step ALONE, forward + backward, on the kernels ltr_train_step runs (split-fp16
+ * MFMA; what autograd does for OPTAttention in train/trainer.py:147-159): for every request r and head,
+ *   out = softmax_causal(q k^T / 8) v    and, given dout = dLoss/dout,    dqkv = (dq | dk | dv).
+ *   qkv f32 [T, 3 hidden] (q | k | v per token, head-major inside each third, as QKVParallelLinear lays them out,
+ *   opt.py:92-102), dout f32 [T, hidden], out f32 [T, hidden], dqkv f32 [T, 3 hidden]; all device.  head size 64.
+ *   workspace: ltr_train_attention_workspace_bytes(num_heads, N, T) bytes. */
+size_t ltr_train_attention_workspace_bytes(int32_t num_heads, int64_t N, int64_t T);
+int ltr_train_attention(int32_t num_heads, const float* qkv, const float* dout, const int32_t* cu_seqlens, int32_t N,
+                        int32_t T, float* out, float* dqkv, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,3 +66,44 @@ def test_attention_kernel_alone_vs_oracle(model, mode, scale_q):
     # outputs are convex combinations of v ~ N(0, 1): absolute tolerance.  f16 path: products of split operands
     # (dropped lo.lo terms 2^-22) + an fp16 hi|lo output; f32 path: plain f32 arithmetic
     assert err.max() <= 3e-6 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("heads,scale_q,dout_scale", [(12, 1.0, 1.0), (12, 4.0, 3e-7), (16, 0.5, 2e3)])
+def test_attention_backward_alone_vs_f64_autograd(heads, scale_q, dout_scale):
+    """The training step's attention backward ALONE (``ltr_train_attention``: split-fp16 MFMA forward + backward)
+    against torch autograd in f64 on the same ragged batch - lengths around every tiling edge (1; 31 / 32 / 33: one key
+    tile; 127 / 128 / 129: one or two blocks; 300; 1024), output gradients from 3e-7 (far below fp16's range: the kernel
+    scales them) to 2e3.  Bar: 2e-5 of each gradient's largest entry, per (request, q / k / v)."""
+    from vllm_ltr_amd.trainer import attention_forward_backward
+    lens = [1, 31, 32, 33, 128, 129, 1024, 5, 64, 65, 1, 300, 127]
+    H = 64 * heads
+    T = int(np.sum(lens))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = _qkv(T, H, 11, scale_q)
+    r = np.random.RandomState(12)
+    do = (r.standard_normal((T, H)) * dout_scale * np.exp(r.standard_normal((T, 1)))).astype(np.float32)   # rows of very different size
+    dev = torch.device("cuda:0")
+    out, dqkv = attention_forward_backward(torch.from_numpy(x).to(dev), torch.from_numpy(do).to(dev), torch.from_numpy(cu).to(dev), heads)
+    out, dqkv = out.double().cpu(), dqkv.double().cpu()
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    worst = 0.0
+    for i, L in enumerate(lens):
+        a, b = int(cu[i]), int(cu[i + 1])
+        xx = torch.from_numpy(x[a:b]).double().requires_grad_(True)
+        q, k, v = (xx[:, j * H:(j + 1) * H].reshape(L, heads, 64).transpose(0, 1) for j in range(3))
+        s = (q @ k.transpose(1, 2)) * 0.125
+        s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+        o = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, H)
+        o.backward(torch.from_numpy(do[a:b]).double())
+        assert (out[a:b] - o.detach()).abs().max() <= 2e-6 * max(1.0, float(o.detach().abs().max())), (i, L)
+        for j, name in enumerate("qkv"):
+            want = xx.grad[:, j * H:(j + 1) * H]
+            got = dqkv[a:b, j * H:(j + 1) * H]
+            # (a one-token prompt has dq = dk = 0 exactly; what the kernel leaves there is the rounding of dP - D:
+            #  an absolute floor of 1e-6 |dO| |x|^2 next to the relative bar)
+            floor = 1e-6 * float(np.abs(do[a:b]).max()) * float(np.abs(x[a:b]).max()) ** 2
+            err = float((got - want).abs().max())
+            rel = err / max(float(want.abs().max()), floor / 2e-5)
+            worst = max(worst, rel)
+            assert rel <= 2e-5, f"request {i} (L = {L}) d{name}: {rel:.2e} of its largest entry"
+    print(f"attention backward, heads={heads} scale_q={scale_q} dout~{dout_scale:g}: worst max-relative error {worst:.2e}")

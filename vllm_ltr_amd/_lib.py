@@ -24,8 +24,9 @@ SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "lt
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
-           "ltr_train_step", "ltr_train_read", "ltr_attention")
-ABI_VERSION = 3
+           "ltr_train_step", "ltr_train_read", "ltr_attention", "ltr_train_attention",
+           "ltr_train_attention_workspace_bytes")
+ABI_VERSION = 4
 
 
 class LtrError(RuntimeError):
@@ -118,9 +119,13 @@ def _load() -> C.CDLL:
     lib.ltr_train_workspace_bytes.restype = sz
     lib.ltr_train_step.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]
     lib.ltr_train_read.argtypes = [vp, i32, i32, vp, sz, C.POINTER(sz), vp]
+    lib.ltr_train_attention_workspace_bytes.argtypes = [i32, i64, i64]
+    lib.ltr_train_attention_workspace_bytes.restype = sz
+    lib.ltr_train_attention.argtypes = [i32, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version", "ltr_train_workspace_bytes"):
+        if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version", "ltr_train_workspace_bytes",
+                        "ltr_train_attention_workspace_bytes"):
             fn.restype = C.c_int
     if lib.ltr_abi_version() != ABI_VERSION:
         raise LtrError(f"{LIB_PATH} has ABI version {lib.ltr_abi_version()}, this binding needs {ABI_VERSION}: rebuild")

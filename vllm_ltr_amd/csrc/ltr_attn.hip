@@ -898,6 +898,14 @@ int launch_attention_lastq(const float* q, AOp kv, const int32_t* cu, int n_req,
   return LTR_OK;
 }
 
+// f32 [n] -> row-major fp16 hi | lo planes (planes[0 .. n) = hi, planes[n .. 2n) = lo), unscaled
+int launch_attention_bwd_planes(const float* x, size_t n, void* planes, hipStream_t s) {
+  const size_t n8 = n / 8;
+  attn_bwd_planes_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>(x, n8, nullptr, nullptr, (__half*)planes, (__half*)planes + n);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
 // Attention backward of the training step (split-fp16 MFMA): dqkv [T, 3H] f32 from the saved qkv / attention output /
 // log-sum-exp rows and the output gradient dout [T, H].  qkv_planes / do_planes: scratch for the fp16 hi | lo planes
 // ([2][T, 3H] and [2][T, H] halves); amax_do / amax_qkv: device slots holding max|dout| and max|qkv|; blk_start: the

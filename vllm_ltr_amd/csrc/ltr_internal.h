@@ -114,6 +114,7 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]
                      int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s,
                      float* lse2 = nullptr /*[T, heads] log2-domain log-sum-exp of every query row (training), nullable*/);
 
+int launch_attention_bwd_planes(const float* x, size_t n /*multiple of 8*/, void* planes /*[2][n] halves*/, hipStream_t s);
 // training: dqkv [T, 3H] of the attention block on the split-fp16 MFMA (ltr_attn.hip "attention BACKWARD")
 int launch_attention_bwd(const float* qkv, const float* o, const float* dout, const float* lse2, const float* amax_do,
                          const float* amax_qkv, const int32_t* blk_start /*128-row work list of launch_attention*/, int n_req,

@@ -1145,4 +1145,53 @@ int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* 
   return LTR_OK;
 }
 
+
+namespace {
+struct AttnWs { __half *qp, *op; float *lse, *Dq, *slots; int32_t* blk; size_t bytes; };
+AttnWs carve_attn(int nh, int64_t N, int64_t T, void* base) {
+  const size_t H = (size_t)nh * D;
+  char* p = (char*)base;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t q = o; o += up(bytes); return base ? p + q : (char*)nullptr; };
+  AttnWs w;
+  w.qp = (__half*)take((size_t)T * 3 * H * 4);            // hi | lo planes of qkv
+  w.op = (__half*)take((size_t)T * H * 4);                // hi | lo planes of out, then of dout
+  w.lse = (float*)take((size_t)T * nh * 4);
+  w.Dq = (float*)take((size_t)T * nh * 4);
+  w.slots = (float*)take(64);
+  w.blk = (int32_t*)take(((size_t)(N + 4) + ((size_t)T / 64 + N + 1) * 4) * 4);
+  w.bytes = o;
+  return w;
+}
+}  // namespace
+
+size_t ltr_train_attention_workspace_bytes(int32_t num_heads, int64_t N, int64_t T) {
+  return carve_attn(num_heads, N, T, nullptr).bytes;
+}
+
+int ltr_train_attention(int32_t num_heads, const float* qkv, const float* dout, const int32_t* cu_seqlens, int32_t N, int32_t T,
+                        float* out, float* dqkv, void* workspace, size_t ws_bytes, void* stream) {
+  if (num_heads <= 0 || N < 0 || T < 0) { set_error("ltr_train_attention: bad argument"); return LTR_E_INVAL; }
+  if (N == 0 || T == 0) return LTR_OK;
+  if (!qkv || !dout || !cu_seqlens || !out || !dqkv || !workspace) { set_error("ltr_train_attention: NULL pointer"); return LTR_E_INVAL; }
+  const AttnWs w = carve_attn(num_heads, N, T, workspace);
+  if (ws_bytes < w.bytes) { set_error("ltr_train_attention: workspace too small (%zu < %zu)", ws_bytes, w.bytes); return LTR_E_NOMEM; }
+  hipStream_t s = (hipStream_t)stream;
+  const int H = num_heads * D;
+  // forward exactly as ltr_train_step runs it: planes of qkv -> MFMA attention (+ log-sum-exp rows) -> f32 out
+  LTR_HIP_CHECK(hipMemsetAsync(w.slots, 0, 64, s));
+  int rc = launch_attention_bwd_planes(qkv, (size_t)T * 3 * H, w.qp, s);
+  if (rc) return rc;
+  AOp planes{w.qp, w.qp + (size_t)T * 3 * H}, op{w.op, w.op + (size_t)T * H};
+  if ((rc = launch_attention(LTR_W_F16, planes, cu_seqlens, N, T, H, num_heads, w.blk, op, 1, s, w.lse))) return rc;
+  const size_t n8 = (size_t)T * H / 8;
+  planes_to_f32_kernel<<<(unsigned)((n8 + 255) / 256), 256, 0, s>>>((const __half*)op.hi, (const __half*)op.lo, out, n8);
+  LTR_LAUNCH_CHECK();
+  amax_kernel<<<(unsigned)std::min<size_t>(((size_t)T * H + 4095) / 4096, AMAX_BLOCKS), 256, 0, s>>>(dout, (size_t)T * H, w.slots);
+  amax_kernel<<<(unsigned)std::min<size_t>(((size_t)T * 3 * H + 4095) / 4096, AMAX_BLOCKS), 256, 0, s>>>(qkv, (size_t)T * 3 * H, w.slots + 1);
+  LTR_LAUNCH_CHECK();
+  return launch_attention_bwd(qkv, out, dout, w.lse, w.slots, w.slots + 1, w.blk, N, T, H, num_heads, 0.125f, w.qp, w.op, w.Dq,
+                              dqkv, s);
+}
+
 }  // extern "C"

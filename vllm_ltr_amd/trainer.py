@@ -277,3 +277,25 @@ class HipPredictorTrainer:
         path = os.path.join(output_dir, "usage_config.json")
         PrefillPredictorConfig.to_json(config, path)
         return path
+
+
+def attention_forward_backward(qkv: torch.Tensor, dout: torch.Tensor, cu_seqlens: torch.Tensor, num_heads: int):
+    """The attention block of the training step alone (``ltr_train_attention``): ``qkv`` f32 [T, 3H], ``dout`` f32 [T, H] and
+    ``cu_seqlens`` int32 [N + 1] on one ROCm device -> ``(out [T, H], dqkv [T, 3H])`` f32.  The kernels ``step()`` runs:
+    split-fp16 MFMA forward with saved log-sum-exp rows, split-fp16 MFMA backward (what autograd does for OPTAttention
+    under train/trainer.py:147-159)."""
+    if not qkv.is_cuda:
+        raise _lib.LtrError("attention_forward_backward needs a ROCm GPU (no CPU fallback on the product path)")
+    lib = _lib.load()
+    T, N = int(qkv.shape[0]), int(cu_seqlens.numel()) - 1
+    H = int(qkv.shape[1]) // 3
+    assert qkv.dtype == torch.float32 and dout.dtype == torch.float32 and cu_seqlens.dtype == torch.int32
+    assert qkv.is_contiguous() and dout.is_contiguous() and dout.shape == (T, H) and H == 64 * num_heads
+    out = torch.empty((T, H), dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty((T, 3 * H), dtype=torch.float32, device=qkv.device)
+    ws = torch.empty(int(lib.ltr_train_attention_workspace_bytes(num_heads, N, T)), dtype=torch.uint8, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.ltr_train_attention(num_heads, qkv.data_ptr(), dout.data_ptr(), cu_seqlens.data_ptr(), N, T,
+                                           out.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), ws.numel(), st), "ltr_train_attention")
+    return out, dqkv
