@@ -337,6 +337,13 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #ifdef LTR_GEMM_TIMELINE
   const unsigned long long tl0 = __builtin_readcyclecounter();
 #endif
+  if (LNM == LN_NONE && !RLN && gridDim.y > 1) {
+    // split-K (GemmArgs::split_k; the weight-gradient GEMMs of the training step: few output tiles, K = the tokens): part
+    // blockIdx.y multiplies its K columns (K = the columns of ONE part; slab-major A) into its own partial output
+    const size_t part = blockIdx.y;
+    a_hi += part * (size_t)K * M; a_lo += part * (size_t)K * M; w += part * (size_t)K * N;
+    ep.out_f32 += part * (size_t)M * N;
+  }
   int tm, tn;
   tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, gm);
   const int m0 = tm * BM, n0 = tn * BN16;
@@ -1005,6 +1012,12 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   if (wdtype != LTR_W_F16 && (g.a_slab || g.out_slab)) { set_error("gemm: slab-major operands exist in F16 mode only"); return LTR_E_INVAL; }
   if (g.out_slab && g.N % 32) { set_error("gemm: slab-major output needs N %% 32 == 0"); return LTR_E_INVAL; }
   dim3 grid(tiles_m * tiles_n);
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  if (split > 1 && (wdtype != LTR_W_F16 || lnm != LN_NONE || rln || !g.a_slab || !g.out_f32 || g.out_split.hi || g.bias || g.resid ||
+                    g.relu || g.K % (BK16 * split))) {
+    set_error("gemm: split_k needs F16 mode, a slab-major A, K %% (32 split_k) == 0 and a plain f32 output [split_k][M][N]");
+    return LTR_E_INVAL;
+  }
   if (wdtype == LTR_W_F16) {
     // Order inside a group of 8 row tiles: M fastest for wide outputs (QKV, fc1: 9-12 column tiles; consecutive
     // workgroups share a weight panel), N fastest for narrow ones (out_proj, fc2: <= 4 column tiles; the column tiles of
@@ -1022,7 +1035,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     // is slower than both its neighbours everywhere (1,382 tokens: 2.21 vs 1.42 ms per call; 5,928: 3.31 vs 3.02;
     // 23,078: 9.58 vs 8.61): not instantiated.
     static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 0; }();
-    const int cfg = gemm_small_config(g);                            // 0: 32 x 64, 1: 64 x 128
+    const int cfg = split > 1 ? -1 : gemm_small_config(g);           // 0: 32 x 64, 1: 64 x 128
     if (cfg >= 0) {
       const int bm = cfg == 0 ? 32 : 64, bnn = cfg == 0 ? 64 : 128;
       {
@@ -1069,9 +1082,10 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
         return LTR_OK;
       }
     }
+    grid.y = split;
 #define LTR_BIG_LAUNCH(LN, RL)                                                                                             \
   gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, \
-                                                g.K, tiles_m, tiles_n, gm, ep)
+                                                g.K / split, tiles_m, tiles_n, gm, ep)
     if (rln) { if (lnm == LNP) LTR_BIG_LAUNCH(LNP, true); else LTR_BIG_LAUNCH(LN_NONE, true); }
     else if (lnm == LNP) LTR_BIG_LAUNCH(LNP, false);
     else if (lnm == LNC) LTR_BIG_LAUNCH(LNC, false);

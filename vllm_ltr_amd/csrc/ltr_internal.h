@@ -81,6 +81,9 @@ struct GemmArgs {
   // not together with the LayerNorm fold.
   const float* osc_a = nullptr;      // device: max|x| of the A operand's source tensor
   const float* osc_b = nullptr;      // device: max|x| of the B operand's source tensor
+  // Split-K (F16 mode, slab-major A, plain f32 output): K is cut into split_k equal parts (each a multiple of 32), part p
+  // writes its partial product to out_f32 + p * M * N; the caller adds the parts up (fixed order).  Always on the 128 x 256 kernel.
+  int split_k = 0;
 };
 
 // launchers (each in its own .hip file)

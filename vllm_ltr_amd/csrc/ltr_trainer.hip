@@ -184,6 +184,22 @@ __global__ void __launch_bounds__(256) planes_to_f32_kernel(const __half* __rest
   *reinterpret_cast<float4*>(out + i * 8 + 4) = *reinterpret_cast<const float4*>(o + 4);
 }
 
+// out = (sum_p partial[p]) / (s_A s_B): the parts of a split-K GEMM added up in part order (deterministic), unscaled
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int parts, size_t n4,
+                                                            const float* __restrict__ amax_a, const float* __restrict__ amax_b,
+                                                            float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float inv = 1.f / (split_scale(*amax_a) * split_scale(*amax_b));
+  const float4* p4 = reinterpret_cast<const float4*>(partial);
+  float4 acc = p4[i];
+  for (int p = 1; p < parts; ++p) {
+    const float4 v = p4[(size_t)p * n4 + i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
 // column sums in two fixed-order stages: partial[b][c] = sum over rows [b * CS_ROWS, ...) ; out[c] = sum_b partial[b][c]
 // (32-row blocks: a slate is a few thousand rows, 256-row blocks left the chip to 12 x 16 workgroups: 71 us per call, 98
 // calls per step)
@@ -613,6 +629,7 @@ size_t weight_count(const ltr_model_desc& d, int idx) {
 }
 
 // workspace carve-up of one step
+constexpr int SPLITK_MAX = 8;        // parts of a split-K weight-gradient GEMM
 constexpr int MAX_GEMMS = 4096;      // split GEMMs per step (a 24-layer model makes ~290)
 struct TrainWs {
   struct Layer { float *x0, *n1, *qkv, *ao, *lse, *mid, *n2, *f, *ao_raw, *mlp_raw; };
@@ -621,7 +638,7 @@ struct TrainWs {
   float *dh, *dbig, *dsmall, *dsmall2, *xhd, *t1, *t2, *partial, *Dq;
   float *opa, *wb;         // split-fp16 GEMM operands of one call: A image hi|lo over 2K, [Bh | Bl] weight image
   float *qkvp, *aop;       // hi | lo planes of qkv [2][T, 3H] and of the attention output [2][T, H] (fp16 path)
-  float* scales;           // max |x| slots of the GEMM operands of the step
+  float *gtmp, *scales;    // partial products of a split-K weight-gradient GEMM; max |x| slots of the GEMM operands of the step
   int32_t* blk;
   int32_t* blk2;     // work list of the MFMA attention forward (fp16 path)
   size_t bytes;
@@ -629,7 +646,7 @@ struct TrainWs {
 
 TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, bool dropout) {
   const size_t H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, nh = d.num_heads, nl = d.num_labels;
-  const size_t Tp = (T + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
+  const size_t Tp = (T + 127) / 128 * 128, Np = (N + 127) / 128 * 128;   // (contraction dims of the weight-gradient GEMMs, padded)
   const size_t big = std::max<size_t>(3 * H, F);
   char* p = (char*)base;
   size_t o = 0;
@@ -647,7 +664,7 @@ TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, b
   w.dh = take(T * H); w.dbig = take(T * big); w.dsmall = take(T * H); w.dsmall2 = take(T * H); w.xhd = take(T * H);
   w.t1 = take(big * Tp); w.t2 = take(big * Tp);
   w.qkvp = take(T * 3 * H + 64); w.aop = take(T * H + 64);           // 2 planes x 2 B = one float per element
-  w.scales = take(MAX_GEMMS * 2);
+  w.gtmp = take((size_t)SPLITK_MAX * big * std::max(H, De) + 64); w.scales = take(MAX_GEMMS * 2);
   w.opa = take(2 * big * Tp + 64);                                   // 2 planes x M x 2K halves = 2 M K floats
   w.wb = take(std::max(std::max(big * Tp, big * H), F * H) + 64);    // N x 2K halves = N K floats
   w.partial = take(((size_t)(T + CS_ROWS - 1) / CS_ROWS + 1) * big);
@@ -707,7 +724,8 @@ bool split_ok(const Ctx& c, const Opnd& a, const Opnd& b) {
 }
 int gemm_split(Ctx& c, Opnd a, Opnd b, const float* bias, const float* resid, float* out, int relu, AOp* planes) {
   hipStream_t s = c.s;
-  const int M = a.rows, N = b.rows, K = (a.kr + 31) / 32 * 32;
+  // (weight gradients: the token dimension is padded to 128 so that it can be cut into up to 4 x 2 equal parts of whole slabs)
+  const int M = a.rows, N = b.rows, K = a.trans && b.trans ? (a.kr + 127) / 128 * 128 : (a.kr + 31) / 32 * 32;
   if (!a.amax) a.amax = amax_of(c, a.p, (size_t)a.rows * a.kr, a.stable);
   if (!b.amax) b.amax = amax_of(c, b.p, (size_t)b.rows * b.kr, b.stable);
   if (!a.amax || !b.amax) return LTR_E_INVAL;
@@ -730,6 +748,24 @@ int gemm_split(Ctx& c, Opnd a, Opnd b, const float* bias, const float* resid, fl
   // before bias / ReLU / residual, and writes the row-major hi | lo planes of the result when asked (QKV for the MFMA attention)
   GemmArgs r{};
   r.a = AOp{ah, al}; r.w = c.ws.wb; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
+  // Weight gradients (both operands transposed): an [N_out, K_out] output is a few dozen 128 x 256 tiles while K = the
+  // tokens of the slate - cut K into parts until the launch has about one workgroup per CU-slot, sum the parts in order
+  if (a.trans && b.trans && !bias && !resid && !relu && !planes) {
+    static const int want = [] { const char* e = getenv("LTR_TRAIN_SPLITK_WGS"); return e ? atoi(e) : 384; }();   // A/B knob, 0 = off
+    const int tiles = ((M + 127) / 128) * ((N + 255) / 256), slabs = 2 * K / 32;
+    int parts = 1;
+    while (want > 0 && parts < SPLITK_MAX && tiles * parts * 2 <= want && slabs % (parts * 2) == 0 && slabs / (parts * 2) >= 16) parts *= 2;
+    if (parts > 1 && (size_t)parts * M * N <= (size_t)SPLITK_MAX * std::max<size_t>(3 * c.t->d.hidden_size, c.t->d.ffn_dim) *
+                                                  std::max(c.t->d.hidden_size, c.t->d.word_embed_proj_dim)) {
+      r.out_f32 = c.ws.gtmp; r.split_k = parts;
+      int rc = launch_gemm(LTR_W_F16, r, s);
+      if (rc) return rc;
+      const size_t n4 = (size_t)M * N / 4;
+      splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, parts, n4, a.amax, b.amax, out);
+      LTR_LAUNCH_CHECK();
+      return LTR_OK;
+    }
+  }
   r.bias = bias; r.resid = resid; r.out_f32 = out; r.relu = relu;
   if (planes) r.out_split = *planes;
   r.osc_a = a.amax; r.osc_b = b.amax;
