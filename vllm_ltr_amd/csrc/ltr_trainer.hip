@@ -184,10 +184,12 @@ __global__ void __launch_bounds__(256) planes_to_f32_kernel(const __half* __rest
   *reinterpret_cast<float4*>(out + i * 8 + 4) = *reinterpret_cast<const float4*>(o + 4);
 }
 
-// out = (sum_p partial[p]) / (s_A s_B): the parts of a split-K GEMM added up in part order (deterministic), unscaled
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int parts, size_t n4,
+// out = (ReLU)((sum_p partial[p]) / (s_A s_B) + bias) + resid: the parts of a split-K GEMM added up in part order
+// (deterministic), unscaled, then what the GEMM epilogue would have applied.  4 consecutive columns per thread.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, int parts, size_t n4, int N,
                                                             const float* __restrict__ amax_a, const float* __restrict__ amax_b,
-                                                            float* __restrict__ out) {
+                                                            const float* __restrict__ bias, const float* resid, int relu,
+                                                            float* out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const float inv = 1.f / (split_scale(*amax_a) * split_scale(*amax_b));
@@ -197,7 +199,17 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     const float4 v = p4[(size_t)p * n4 + i];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
-  reinterpret_cast<float4*>(out)[i] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+  if (bias) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % N);
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+  if (resid) {
+    const float4 r = reinterpret_cast<const float4*>(resid)[i];
+    acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = acc;
 }
 
 // column sums in two fixed-order stages: partial[b][c] = sum over rows [b * CS_ROWS, ...) ; out[c] = sum_b partial[b][c]
@@ -641,6 +653,7 @@ struct TrainWs {
   float *gtmp, *scales;    // partial products of a split-K weight-gradient GEMM; max |x| slots of the GEMM operands of the step
   int32_t* blk;
   int32_t* blk2;     // work list of the MFMA attention forward (fp16 path)
+  size_t gtmp_floats;
   size_t bytes;
 };
 
@@ -664,7 +677,8 @@ TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, b
   w.dh = take(T * H); w.dbig = take(T * big); w.dsmall = take(T * H); w.dsmall2 = take(T * H); w.xhd = take(T * H);
   w.t1 = take(big * Tp); w.t2 = take(big * Tp);
   w.qkvp = take(T * 3 * H + 64); w.aop = take(T * H + 64);           // 2 planes x 2 B = one float per element
-  w.gtmp = take((size_t)SPLITK_MAX * big * std::max(H, De) + 64); w.scales = take(MAX_GEMMS * 2);
+  w.gtmp_floats = std::max((size_t)SPLITK_MAX * big * std::max(H, De), (size_t)4 * Tp * H);
+  w.gtmp = take(w.gtmp_floats + 64); w.scales = take(MAX_GEMMS * 2);
   w.opa = take(2 * big * Tp + 64);                                   // 2 planes x M x 2K halves = 2 M K floats
   w.wb = take(std::max(std::max(big * Tp, big * H), F * H) + 64);    // N x 2K halves = N K floats
   w.partial = take(((size_t)(T + CS_ROWS - 1) / CS_ROWS + 1) * big);
@@ -748,20 +762,22 @@ int gemm_split(Ctx& c, Opnd a, Opnd b, const float* bias, const float* resid, fl
   // before bias / ReLU / residual, and writes the row-major hi | lo planes of the result when asked (QKV for the MFMA attention)
   GemmArgs r{};
   r.a = AOp{ah, al}; r.w = c.ws.wb; r.M = M; r.N = N; r.K = 2 * K; r.a_slab = 1;
-  // Weight gradients (both operands transposed): an [N_out, K_out] output is a few dozen 128 x 256 tiles while K = the
-  // tokens of the slate - cut K into parts until the launch has about one workgroup per CU-slot, sum the parts in order
-  if (a.trans && b.trans && !bias && !resid && !relu && !planes) {
+  // Few output tiles, long K (weight gradients: an [N_out, K_out] output while K = the tokens of the slate; the 768-wide
+  // outputs of a 4k-token slate: 93 tiles for 512 workgroup slots): cut K into parts until the launch has about one
+  // workgroup per slot, add the parts up in order and apply the epilogue there
+  if (!planes) {
     static const int want = [] { const char* e = getenv("LTR_TRAIN_SPLITK_WGS"); return e ? atoi(e) : 384; }();   // A/B knob, 0 = off
+    static const int narrow = [] { const char* e = getenv("LTR_TRAIN_SPLITK_NARROW"); return e ? atoi(e) : 1; }(); // 0: weight gradients only
     const int tiles = ((M + 127) / 128) * ((N + 255) / 256), slabs = 2 * K / 32;
     int parts = 1;
-    while (want > 0 && parts < SPLITK_MAX && tiles * parts * 2 <= want && slabs % (parts * 2) == 0 && slabs / (parts * 2) >= 16) parts *= 2;
-    if (parts > 1 && (size_t)parts * M * N <= (size_t)SPLITK_MAX * std::max<size_t>(3 * c.t->d.hidden_size, c.t->d.ffn_dim) *
-                                                  std::max(c.t->d.hidden_size, c.t->d.word_embed_proj_dim)) {
+    if ((a.trans && b.trans) || narrow)
+      while (want > 0 && parts < SPLITK_MAX && tiles * parts * 2 <= want && slabs % (parts * 2) == 0 && slabs / (parts * 2) >= 16) parts *= 2;
+    if (parts > 1 && (size_t)parts * M * N <= c.ws.gtmp_floats) {
       r.out_f32 = c.ws.gtmp; r.split_k = parts;
       int rc = launch_gemm(LTR_W_F16, r, s);
       if (rc) return rc;
       const size_t n4 = (size_t)M * N / 4;
-      splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, parts, n4, a.amax, b.amax, out);
+      splitk_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(c.ws.gtmp, parts, n4, N, a.amax, b.amax, bias, resid, relu, out);
       LTR_LAUNCH_CHECK();
       return LTR_OK;
     }
