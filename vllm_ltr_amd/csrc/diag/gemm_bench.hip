@@ -22,6 +22,12 @@ __global__ void fill_f32(float* p, size_t n, float scale, float off, unsigned se
     p[i] = ((float)(x & 0xffff) / 32768.f - 1.f) * scale + off;
   }
 }
+// ReLU-shaped operand (probe builds whose fc1 does not store: fc2 must still see what fc1 writes in the model - half the
+// entries zero in BOTH planes - because MFMA power, and with it the clock, depends on the data)
+__global__ void relu_planes(__half* hi, __half* lo, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (__half2float(hi[i]) < 0.f) { hi[i] = __float2half(0.f); lo[i] = __float2half(0.f); }
+}
 template <class T> T* alloc(size_t n) { T* p; if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) { printf("alloc failed\n"); exit(1); } return p; }
 
 int main(int argc, char** argv) {
@@ -36,6 +42,7 @@ int main(int argc, char** argv) {
   float2* st2 = alloc<float2>((size_t)(H / 64) * M);
   fill_half<<<2048, 256>>>(a, (size_t)M * H, 1.f, 1); fill_half<<<2048, 256>>>(a + (size_t)M * H, (size_t)M * H, 2e-4f, 2);
   fill_half<<<2048, 256>>>(f, (size_t)M * F, 1.f, 3); fill_half<<<2048, 256>>>(f + (size_t)M * F, (size_t)M * F, 2e-4f, 4);
+  relu_planes<<<2048, 256>>>(f, f + (size_t)M * F, (size_t)M * F);
   fill_f32<<<2048, 256>>>(h, (size_t)M * H, 1.f, 0.f, 5);
   fill_f32<<<2048, 256>>>((float*)st1, (size_t)(H / 64) * M * 2, 0.1f, 1.f, 6);
   fill_f32<<<2048, 256>>>((float*)st2, (size_t)(H / 64) * M * 2, 0.1f, 1.f, 7);

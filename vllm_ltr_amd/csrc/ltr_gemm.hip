@@ -358,7 +358,13 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const int row = wave * 16 + (lane >> 2);
     const int c_log = (lane & 3) ^ swz(row);
     // rows past M/N: any valid row, masked later.  Row-major: row pitch K; slab-major: row pitch 32, slab pitch M*32
+#ifdef LTR_GEMM_AROW_MOD   // diag (wrong results): every row tile of a K = 3072 GEMM reads the same few A rows - an L2-resident
+                           // stand-in for "the fc1 -> fc2 intermediate never goes to memory" (profiles/r03_fused_and_fp8_probes.txt)
+    const int arow = K == 3072 ? min(m0 + row, M - 1) % LTR_GEMM_AROW_MOD : min(m0 + row, M - 1);
+    const size_t aoff = (size_t)arow * (ep.a_slab ? BK16 : K) + c_log * 8;
+#else
     const size_t aoff = (size_t)min(m0 + row, M - 1) * (ep.a_slab ? BK16 : K) + c_log * 8;
+#endif
     ga = a_hi + aoff;
     gl = a_lo + aoff;
 #pragma unroll
@@ -374,8 +380,15 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const size_t ka = (size_t)(k0 / BK16) * a_slab, kw = (size_t)(k0 / BK16) * w_slab;
     // (default cache policy on purpose: the non-temporal hint on the activation stream costs 5 % of the call for the
     // narrow GEMMs alone and 11 % for all - the co-resident tiles share these lines through the L2)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(ga + ka), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
+#ifdef LTR_GEMM_A_ONCE   // diag (wrong results): a K = 3072 GEMM streams its A operand for the first two slabs only and multiplies
+                         // those (valid, LDS-resident) fragments ever after - "the fc1 -> fc2 intermediate is already in LDS"
+    if (K != 3072 || k0 < 2 * BK16) {
+#else
+    {
+#endif
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ga + ka), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void*)(gw[i] + kw),
