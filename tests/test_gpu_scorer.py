@@ -740,3 +740,33 @@ def test_config5_ranker_side_trace_replay(dev, kind):
     else:
         assert s["ranker_ms_with_arrivals"]["n"] > 20
     assert s["ranker_ms_steady"]["p50"] < 5.0
+
+
+@pytest.mark.parametrize("name,hidden,ffn,heads,pre_ln,embed", [("1.3b", 2048, 8192, 32, True, 2048),
+                                                                  ("350m-wide", 1536, 6144, 24, False, 768)])
+def test_wider_opt_shapes_two_layers(dev, name, hidden, ffn, heads, pre_ln, embed):
+    """The OPT family beyond the two predictors of the benchmark (the reference takes any HF OPT checkpoint through
+    `OPTForSequenceClassification`, opt.py:349-397): two layers at the width of OPT-1.3b (H = 2048, 32 heads, FFN 8192:
+    32 statistics pieces per row in the LayerNorm fold, K = 8192 in fc2) and a post-LN / project_in-out shape wider than
+    OPT-350m, small vocabulary.  Oracle on every request, one-request-at-a-time against the batch (small- vs large-tile
+    kernels), fold on / off."""
+    spec = OPTSpec(vocab_size=4096, hidden_size=hidden, ffn_dim=ffn, num_hidden_layers=2, num_attention_heads=heads,
+                   word_embed_proj_dim=embed, max_position_embeddings=512, do_layer_norm_before=pre_ln, num_labels=1)
+    ckpt = seeded_checkpoint(spec, 3)
+    lens = [1, 2, 17, 31, 32, 33, 64, 100, 128, 129, 200, 300, 5, 77, 256, 450]
+    ids, cu = synthetic_batch(spec, lens, 5)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    got = sc.score(ids, cu)
+    want = OracleOPTScorer(spec, ckpt).score(ids, cu)
+    err = np.abs(got - want).max()
+    print(f"OPT {name} shape, 2 layers: max|score - oracle| = {err:.3e}")
+    assert np.isfinite(got).all() and err <= TOL
+    for i in (0, 5, 11, 15):                                          # alone (small-tile kernels) = inside the batch, bit for bit
+        one = sc.score(ids[cu[i]:cu[i + 1]], np.array([0, lens[i]], np.int32))
+        assert one[0] == got[i], (i, one[0], got[i])
+    os.environ["LTR_NO_LN_FOLD"] = "1"
+    try:
+        plain = _scorer(spec, ckpt, dev, "f16")
+    finally:
+        del os.environ["LTR_NO_LN_FOLD"]
+    assert np.abs(plain.score(ids, cu) - got).max() <= 2e-5
