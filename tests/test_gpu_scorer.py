@@ -697,8 +697,9 @@ def test_layernorm_fold_on_and_off_agree(dev, monkeypatch, variant):
         assert np.abs(got - wantk).max() <= 2e-4 * max(1.0, np.abs(wantk).max()), k
 
 
+@pytest.mark.parametrize("family", ["tiny_pre_ln", "tiny_post_ln"])     # the OPT-125m and the OPT-350m (config 5's predictor) block structure
 @pytest.mark.parametrize("kind", ["burst", "gamma"])
-def test_config5_ranker_side_trace_replay(dev, kind):
+def test_config5_ranker_side_trace_replay(dev, kind, family):
     """BASELINE config 5, the ranker's share: a burst (everything at t = 0, benchmarks/burst-*.sh) and a gamma arrival
     process (benchmark_serving_real.py:159-176) replayed through MI355XRanker.install() on an (unpatched) scheduler
     loop - per step k arrivals -> obtain_aux_scores(k) + order + aging.  EVERY step's order is compared with the
@@ -707,7 +708,7 @@ def test_config5_ranker_side_trace_replay(dev, kind):
     from oracle import rank_step as rs
     from vllm_ltr_amd.plugin import MI355XRanker
     from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
-    spec = OPTSpec.tiny_pre_ln()
+    spec = getattr(OPTSpec, family)()
     sc = _scorer(spec, seeded_checkpoint(spec, 4), dev, "f16")
     ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=150)
     reqs = synthetic_trace(spec.vocab_size, 400, kind, request_rate=200.0, cv=2.0, seed=1, prompt_median=24.0,
