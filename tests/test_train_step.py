@@ -239,7 +239,7 @@ def test_fit_loop_with_kendall_tau_and_refused_losses():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["split", "f32"])
-@pytest.mark.parametrize("model,layers", [("125m", 1), ("350m", 1), ("125m", 12), ("350m", 24)])
+@pytest.mark.parametrize("model,layers", [("125m", 1), ("350m", 1), ("125m", 12), ("350m", 24), ("125m-long", 1), ("350m-long", 1)])
 def test_hip_training_step_at_true_shapes(model, layers, precision):
     """One ListMLE step at the true OPT-125m / OPT-350m widths (the shapes the reference fine-tunes, train/train.sh)
     against the oracle's autograd in f64: loss, logits and the gradient of every parameter tensor.
@@ -254,10 +254,16 @@ def test_hip_training_step_at_true_shapes(model, layers, precision):
     import dataclasses
     from vllm_ltr_amd.opt_spec import OPTSpec
     from vllm_ltr_amd.trainer import HipPredictorTrainer
+    # "-long": a slate of ~750 tokens - the weight-gradient GEMMs then contract over enough K-slabs for the split-K path
+    # (GemmArgs::split_k, parts added up in order), which the short slates never reach
+    long_slate = model.endswith("-long")
+    model = model.split("-")[0]
     spec = dataclasses.replace(OPTSpec.opt_125m() if model == "125m" else OPTSpec.opt_350m(), num_hidden_layers=layers)
     ckpt = seeded_checkpoint(spec, 3)
     r = np.random.RandomState(11)
     lens = [9, 1, 40, 64, 17, 33] if model == "125m" else [12, 3, 45, 30]
+    if long_slate:
+        lens = [300, 257, 129, 64]
     ids = np.concatenate([np.r_[2, r.randint(4, spec.vocab_size, L - 1)] for L in lens]).astype(np.int64)
     cu = np.r_[0, np.cumsum(lens)].astype(np.int32)
     labels = r.permutation(len(lens)).astype(np.float32)
