@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""BASELINE config 1 ("OPT-125m predictor, 256-request queue, CPU reference scheduler path") run by the REFERENCE
+ITSELF, end to end: the reference's own ``vllm.core.scheduler.Scheduler`` (chunked prefill, ``opt-xxx-starv200-period10``)
+with the reference's own fp32 ``OPTForSequenceClassification`` standing where ``llm_engine.py:228-242`` puts the AUXLLM.
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python oracle/make_config1_golden.py
+
+Build container only (the GPU box has no /root/reference).  Writes ``tests/golden/config1_opt125m_256.npz``: the
+queue (ids, cu_seqlens - ``bench.synthetic_queue(spec, 256, seed 0)``: T = 23,078), the 256 scores the reference
+predictor produced, and per scheduler step of three runs the three deques, the order ``_get_ordered_requests`` returned,
+the ``ran`` set, the budget-walk inputs and the starvation counters after the aging loop:
+
+* run ``a``: config 1 as BASELINE.json words it (starv 200 / period 10, 2,048-token / 256-sequence budget), 64 requests
+  at step 0 and 8 arrivals per step after that, 36 steps; every arrival batch scored by the reference predictor;
+* run ``b``: the same scores under ``starv6-period2`` with a tight budget, so that promotions / demotions fire
+  (scheduler.py:984-993) - the scores come from run a's reference predictor calls;
+* run ``c`` = run a again with the PRODUCT's ``MI355XRanker.install()`` wiring on the same real ``Scheduler``
+  (``plugin.py``; device pieces replaced by recording doubles - there is no GPU here): pins the attribute surface
+  ``install()`` touches (scheduler.py:290-331,1101-1105,1337-1365) and must reproduce run a's orders and counters.
+
+Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_golden as mg  # noqa: E402  (import shims + scheduler helpers; asserts vllm is /root/reference)
+import torch  # noqa: E402
+
+from bench import synthetic_queue  # noqa: E402
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint  # noqa: E402
+
+GOLD = mg.GOLD
+N_REQ = 256
+
+
+class RefPredictor:
+    """The reference's own OPTForSequenceClassification (fp32, TorchSDPA backend), driven like
+    ModelRunner.execute_model drives it for a prefill batch (model_runner.py:827-877), FCFS packs of <= 2048 tokens
+    per forward like the AUX engine's scheduler (config.py:578-586)."""
+
+    def __init__(self, spec, ckpt):
+        from transformers import OPTConfig
+        from vllm.model_executor.models.opt import OPTForSequenceClassification as REF
+        self.cfg = OPTConfig(**spec.to_hf_config_kwargs())
+        torch.manual_seed(0)
+        self.ref = REF(self.cfg).eval().float()
+        self.ref.load_weights([(k, torch.from_numpy(v.astype(np.float32))) for k, v in ckpt.items()])
+        self.calls = []          # request ids per obtain_aux_scores call
+        self.seconds = 0.0
+
+    def _forward(self, rows):
+        from vllm.attention.backends.torch_sdpa import TorchSDPAMetadata
+        from vllm.model_executor.sampling_metadata import SamplingMetadata
+        lens = [len(r) for r in rows]
+        N, T = len(lens), sum(lens)
+        ids = torch.from_numpy(np.concatenate(rows).astype(np.int64))
+        pos = torch.cat([torch.arange(L) for L in lens]).long()
+        sel = torch.as_tensor(np.cumsum(lens).astype(np.int64) - 1)
+        md = TorchSDPAMetadata(context_lens=None, max_context_len=None, block_tables=torch.tensor([]),
+                               num_prefills=N, num_prefill_tokens=T, num_decode_tokens=0, prefill_metadata=object(),
+                               decode_metadata=None, slot_mapping=torch.zeros(T, dtype=torch.long), kv_cache_dtype="auto",
+                               need_score=False, selected_token_indices=sel, is_prompt=True, prompt_lens=lens)
+        sm = SamplingMetadata(seq_groups=[], seq_data={}, prompt_lens=lens, selected_token_indices=sel,
+                              categorized_sample_indices=None, generators=None, perform_sampling=False)
+        with torch.no_grad():
+            hs, _ = self.ref(ids, pos, [None] * self.cfg.num_hidden_layers, md)
+            return self.ref.compute_logits(hs, sm)[:, 0].float().tolist()          # opt.py:399-409 .tolist()
+
+    def obtain_aux_scores(self, sgs):                      # AUXLLM.obtain_aux_scores (aux_llm.py:125-126)
+        t0 = time.time()
+        self.calls.append([sg.request_id for sg in sgs])
+        pack, tok, out = [], 0, []
+        for sg in sgs:
+            assert sg.need_aux_model_score()               # aux_llm_engine.py:409
+            row = np.asarray(sg.prompt_token_ids, np.int64)
+            if pack and tok + len(row) > 2048:
+                out += self._forward(pack)
+                pack, tok = [], 0
+            pack.append(row)
+            tok += len(row)
+        if pack:
+            out += self._forward(pack)
+        for sg, s in zip(sgs, out):
+            sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
+        self.seconds += time.time() - t0
+
+
+def mk_sg(rid: int, token_ids, block_size=16):
+    from vllm import SamplingParams
+    from vllm.sequence import Sequence, SequenceGroup
+    seq = Sequence(rid, "p", [int(t) for t in token_ids], block_size)
+    return SequenceGroup(str(rid), [seq], SamplingParams(max_tokens=10**6, ignore_eos=True), time.time())
+
+
+def run(tag, schedule_type, aux, ids, cu, arrive_at, steps, max_tokens, max_seqs, out, install=None):
+    """Multi-step run of the reference's Scheduler.schedule(); records what a replay needs (see module docstring).
+    ``install``: callable(scheduler) that wires a ranker INSTEAD of assigning aux_model directly."""
+    from vllm.sequence import Logprob, SequenceStatus
+    n = len(cu) - 1
+    s = mg._mk_scheduler(schedule_type, max_tokens, max_seqs, blocks=8192)
+    if install is None:
+        s.aux_model = aux
+    else:
+        install(s)
+    sgs = [mk_sg(i, ids[cu[i]:cu[i + 1]]) for i in range(n)]
+    captured = {}
+    inner = s._get_ordered_requests
+
+    def spy():
+        captured["deques"] = (len(s.waiting), len(s.running), len(s.swapped))
+        captured["concat"] = [int(g.request_id) for g in list(s.waiting) + list(s.running) + list(s.swapped)]
+        o = inner()
+        captured["order"] = [int(g.request_id) for g in o]
+        return o
+    s._get_ordered_requests = spy
+    rec = {k: [] for k in ("concat", "order", "deques", "ran", "states", "need_tokens", "need_seqs", "chunkable", "granted")}
+    for step in range(steps):
+        for i in np.nonzero(arrive_at == step)[0]:
+            s.add_seq_group(sgs[i])
+        nd = np.zeros(n, np.int32); nq = np.zeros(n, np.int32); ck = np.zeros(n, np.uint8)
+        for dq, status in ((s.waiting, SequenceStatus.WAITING), (s.running, SequenceStatus.RUNNING),
+                           (s.swapped, SequenceStatus.SWAPPED)):
+            for g in dq:
+                seqs = g.get_seqs(status=status)
+                nd[int(g.request_id)] = sum(q.get_num_new_tokens() for q in seqs)     # scheduler.py:1878-1881
+                nq[int(g.request_id)] = g.get_max_num_running_seqs()
+                ck[int(g.request_id)] = len(seqs) == 1                                # :1884
+        metas, o = s.schedule()
+        gr = np.zeros(n, np.int32)
+        ran = np.zeros(n, np.uint8)
+        for x, meta in zip(o.scheduled_seq_groups, metas):
+            g = x.seq_group
+            ran[int(g.request_id)] = 1
+            gr[int(g.request_id)] = meta.token_chunk_size * len(g.get_seqs(status=SequenceStatus.RUNNING))
+            g.update_num_computed_tokens(meta.token_chunk_size)
+            if not g.is_prefill():
+                for seq in g.get_seqs(status=SequenceStatus.RUNNING):
+                    seq.append_token_id(1, {1: Logprob(0.0)})
+        c = np.full(n, -1, np.int32); c[:len(captured["concat"])] = captured["concat"]
+        od = np.full(n, -1, np.int32); od[:len(captured["order"])] = captured["order"]
+        st = np.zeros((n, 3), np.int32)
+        for g in sgs:
+            if hasattr(g, "pri"):
+                st[int(g.request_id)] = (g.pri, g.idle, g.runs)
+        for k, v in (("concat", c), ("order", od), ("deques", np.asarray(captured["deques"], np.int32)), ("ran", ran),
+                     ("states", st), ("need_tokens", nd), ("need_seqs", nq), ("chunkable", ck), ("granted", gr)):
+            rec[k].append(v)
+    for k, v in rec.items():
+        out[f"{tag}_{k}"] = np.stack(v)
+    starv, period = s.starv, getattr(s, "period", 0)
+    out[f"{tag}_starv"], out[f"{tag}_period"] = np.int64(starv), np.int64(period)
+    out[f"{tag}_arrive_at"] = arrive_at.astype(np.int32)
+    out[f"{tag}_token_budget"], out[f"{tag}_max_num_seqs"] = np.int64(max_tokens), np.int64(max_seqs)
+    promoted = int((np.stack(rec["states"])[:, :, 0] == -1).any(axis=0).sum())
+    chunked = int(((np.stack(rec["granted"]) > 0) & (np.stack(rec["granted"]) < np.stack(rec["need_tokens"]))).sum())
+    print(f"run {tag}: {schedule_type}, {steps} steps, budget {max_tokens}/{max_seqs}: requests ever promoted {promoted}, "
+          f"chunked grants {chunked}, first order {rec['order'][0][:8].tolist()}")
+    return s, sgs, rec
+
+
+class ScoreTable:
+    """Stands where the AUXLLM stands with scores a reference predictor call produced earlier (run a)."""
+
+    def __init__(self, table):
+        self.table, self.calls = table, []
+
+    def obtain_aux_scores(self, sgs):
+        self.calls.append([sg.request_id for sg in sgs])
+        for sg in sgs:
+            assert sg.need_aux_model_score()
+            sg.set_aux_model_score(self.table[sg.request_id])
+
+
+def recording_ranker(schedule_type, aux, log):
+    """The PRODUCT's MI355XRanker with its device pieces replaced by recording doubles (no GPU in the build
+    container): install(), ordered_requests() and the wrapped _schedule are plugin.py's own code; scoring goes to the
+    reference predictor / score table, the order to the oracle's literal restatement on the HOST attributes (which
+    the reference's own aging loop, scheduler.py:1358-1365, keeps up to date)."""
+    from oracle import rank_step as rs
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.schedule_type import parse_schedule_type
+
+    class RecordingRanker(MI355XRanker):
+        def __init__(self):
+            self.st = parse_schedule_type(schedule_type)
+            self.xpt_distribution = None
+            self._aged = True
+
+        def obtain_aux_scores(self, seq_groups):
+            log.append(["obtain_aux_scores", len(seq_groups)])
+            aux.obtain_aux_scores(seq_groups)
+            return [sg.aux_model_score for sg in seq_groups]
+
+        def order(self, reqs, policy=None, want_list=True):
+            self._aged = False
+            log.append(["order", len(reqs)])
+            return rs.opt_order(reqs, self.st.starv, self.st.period)
+
+        def age(self, all_pri, running_this_step):
+            self._aged = True
+            log.append(["age", len(all_pri), len(list(running_this_step))])
+
+        def _gc_slots(self, n):
+            pass
+    return RecordingRanker()
+
+
+def main():
+    mg._init_dist()
+    torch.set_num_threads(os.cpu_count())
+    spec = OPTSpec.opt_125m()
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = synthetic_queue(spec, N_REQ, seed=0)
+    assert int(cu[-1]) == 23078, int(cu[-1])                   # BASELINE.md section 3 / SURVEY 8d
+    out = dict(ids=ids.astype(np.int32), cu_seqlens=cu, seed=np.int64(0))
+
+    # ---- run a: config 1, every arrival batch scored by the reference's own predictor
+    arrive_a = np.zeros(N_REQ, np.int32)
+    arrive_a[64:] = 1 + (np.arange(N_REQ - 64) // 8)           # 64 at step 0, then 8 per step (steps 1..24)
+    pred = RefPredictor(spec, ckpt)
+    t0 = time.time()
+    s_a, sgs_a, rec_a = run("a", "opt-xxx-starv200-period10", pred, ids, cu, arrive_a, 36, 2048, 256, out)
+    scores = np.array([g.aux_model_score for g in sgs_a], np.float64)
+    assert np.isfinite(scores).all() and len(pred.calls) == 25 and sum(map(len, pred.calls)) == N_REQ
+    out["ref_score"] = scores.astype(np.float32)
+    assert np.array_equal(out["ref_score"].astype(np.float64), scores)      # fp32 values widened by .tolist()
+    out["a_aux_calls"] = np.array([len(c) for c in pred.calls], np.int32)
+    print(f"run a: {len(pred.calls)} predictor calls, {pred.seconds:.1f} s in the reference predictor "
+          f"({N_REQ / pred.seconds:.1f} req/s on {os.cpu_count()} threads), total {time.time()-t0:.1f} s; "
+          f"score range [{scores.min():.4f}, {scores.max():.4f}], smallest gap between sorted scores "
+          f"{np.diff(np.sort(scores)).min():.3e}")
+
+    # ---- run b: the same scores, starvation control biting (tight budget, early promotions)
+    table = {str(i): float(out["ref_score"][i]) for i in range(N_REQ)}
+    arrive_b = np.sort(np.random.RandomState(5).randint(0, 20, N_REQ)).astype(np.int32)
+    run("b", "opt-xxx-starv6-period2", ScoreTable(table), ids, cu, arrive_b, 48, 512, 24, out)
+
+    # ---- run c: run a through the product's install() wiring on the same real Scheduler
+    log = []
+    surface = {}
+
+    def install(s):
+        for name in ("_general_schedule", "_schedule", "_update_priority", "_get_ordered_requests", "waiting", "running",
+                     "swapped", "need_score", "starv", "period"):
+            surface[name] = type(getattr(s, name)).__name__               # all exist on the real object BEFORE install
+        assert not hasattr(s, "aux_model")                     # a plain attribute the engine assigns after construction (llm_engine.py:228-242)
+        rk = recording_ranker("opt-xxx-starv200-period10", ScoreTable(table), log)
+        rk.install(s)
+        assert s.aux_model is rk and s._schedule.__wrapped__ == s._general_schedule
+    s_c, sgs_c, rec_c = run("c", "opt-xxx-starv200-period10", None, ids, cu, arrive_a, 36, 2048, 256, out, install=install)
+    o = s_c._schedule()                                        # the wrapper's view of the step outputs (plugin.py install)
+    surface["SchedulerOutputs.scheduled_seq_groups"] = type(o.scheduled_seq_groups).__name__
+    if o.scheduled_seq_groups:
+        surface["scheduled_seq_groups[i].seq_group"] = type(o.scheduled_seq_groups[0].seq_group).__name__
+    for k in ("order", "concat", "ran", "states", "granted"):
+        assert np.array_equal(np.stack(rec_c[k]), np.stack(rec_a[k])), k      # the wiring changes nothing
+    # one order + one age per step, an obtain_aux_scores exactly in the steps with arrivals
+    kinds = [e[0] for e in log]
+    assert kinds.count("order") == 37 and kinds.count("age") == 37 and kinds.count("obtain_aux_scores") == 25
+    for k in [k for k in out if k.startswith("c_")]:
+        del out[k]                                             # identical to run a: not stored twice
+    out["surface"] = np.array(json.dumps(dict(attributes=surface, calls=log[:12])))
+    print("install() surface on the real Scheduler:", surface)
+    path = os.path.join(GOLD, "config1_opt125m_256.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
+if __name__ == "__main__":
+    main()

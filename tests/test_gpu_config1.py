@@ -1,0 +1,151 @@
+"""-m gpu: BASELINE config 1 (OPT-125m predictor, 256-request queue, T = 23,078) END TO END against the reference's own run.
+
+``tests/golden/config1_opt125m_256.npz`` (oracle/make_config1_golden.py) was recorded from the reference's own
+``Scheduler`` (scheduler.py:969-1000,1101-1373) with the reference's own fp32 ``OPTForSequenceClassification`` standing
+where the AUXLLM stands (aux_llm_engine.py:398-410).  Here the same steps go through ``MI355XRanker.install()``:
+
+* scores: the HIP predictor on all 256 prompts within 1e-4 of the reference predictor's (north_star);
+* order, given the reference's scores: every step of both runs bit-identical (ties by position in the concatenation);
+* order END TO END - HIP scores -> HIP sort, the order a live scheduler would see: the discordant pairs against the
+  reference's order are counted per step, and every one of them must be a near-tie of the reference's fp32 scores
+  (gap <= 2 x the measured score error): "permutation-identical" holds wherever fp32 itself decides the order.
+"""
+import os
+from collections import deque
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, FakeSeqGroup, discordant_pairs
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def scorer():
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.opt_125m()
+    return HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
+
+
+class ReplayScheduler:
+    """The attribute surface of the reference's Scheduler that install() touches (pinned on the real object by
+    oracle/make_config1_golden.py run c), replaying a RECORDED run: the three deques of every step and the set that ran
+    come from the recording, the order comes from the ranker."""
+
+    def __init__(self, z, tag, groups):
+        self.z, self.tag, self.groups = z, tag, groups
+        self.waiting, self.running, self.swapped = deque(), deque(), deque()
+        self.need_score, self.starv, self.period = False, -1, 0
+        self.step = 0
+        self.orders = []
+        self._schedule = self._general_schedule
+
+    def load_step(self, step):
+        z, tag = self.z, self.tag
+        concat = z[f"{tag}_concat"][step]
+        concat = concat[concat >= 0]
+        nw, nr, ns = (int(x) for x in z[f"{tag}_deques"][step])
+        assert nw + nr + ns == len(concat)
+        g = [self.groups[int(i)] for i in concat]
+        self.waiting, self.running, self.swapped = deque(g[:nw]), deque(g[nw:nw + nr]), deque(g[nw + nr:])
+        self.step = step
+
+    def _update_priority(self):
+        raise AssertionError("install() must rebind _update_priority (scheduler.py:935,1002: a no-op for score-ordered policies)")
+
+    def _get_ordered_requests(self):
+        raise AssertionError("install() must rebind _get_ordered_requests")
+
+    def _general_schedule(self):                      # the shape of scheduler.py:1101-1373 around the ordering
+        self._update_priority()
+        order = self._get_ordered_requests()
+        self.orders.append([int(g.request_id) for g in order])
+        ran = np.nonzero(self.z[f"{self.tag}_ran"][self.step])[0]
+        return SimpleNamespace(scheduled_seq_groups=[SimpleNamespace(seq_group=self.groups[int(i)]) for i in ran])
+
+
+def _groups(z):
+    ids, cu = z["ids"].astype(np.int64), z["cu_seqlens"]
+    return [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(len(cu) - 1)]
+
+
+def _replay(z, tag, scorer, preset_scores):
+    from vllm_ltr_amd.plugin import MI355XRanker
+    starv, period = int(z[f"{tag}_starv"]), int(z[f"{tag}_period"])
+    groups = _groups(z)
+    if preset_scores is not None:
+        for g, s in zip(groups, preset_scores):
+            g.set_aux_model_score(float(s))
+    ranker = MI355XRanker(scorer, f"opt-xxx-starv{starv}-period{period}", max_length=2048)
+    s = ReplayScheduler(z, tag, groups)
+    ranker.install(s)
+    assert s.aux_model is ranker and s.need_score and s.starv == starv and s.period == period
+    steps = z[f"{tag}_order"].shape[0]
+    for step in range(steps):
+        s.load_step(step)
+        s._schedule()
+        alive = list(s.waiting) + list(s.running) + list(s.swapped)
+        ranker.sync_host(alive)
+        st = z[f"{tag}_states"][step]
+        assert all((g.pri, g.idle, g.runs) == tuple(st[int(g.request_id)]) for g in alive), (tag, step)
+    return s.orders, groups, ranker
+
+
+def test_config1_hip_scores_vs_reference_predictor(z, scorer):
+    got = scorer.score(z["ids"].astype(np.int64), z["cu_seqlens"])
+    err = np.abs(got - z["ref_score"])
+    print(f"config 1: HIP predictor vs the reference's fp32 predictor over 256 requests (23,078 tokens): "
+          f"max|d| = {err.max():.3e}, rms {np.sqrt((err ** 2).mean()):.3e}")
+    assert err.max() <= TOL
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_config1_order_bit_identical_given_reference_scores(z, scorer, tag):
+    orders, _, ranker = _replay(z, tag, scorer, z["ref_score"])
+    for step, got in enumerate(orders):
+        want = z[f"{tag}_order"][step]
+        assert got == want[want >= 0].tolist(), (tag, step)
+    assert ranker.stats["aux_calls"] == 0                      # every score came with the request (adoption path)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_config1_end_to_end_order_hip_scores_hip_sort(z, scorer, tag):
+    orders, groups, ranker = _replay(z, tag, scorer, None)
+    ref = z["ref_score"]
+    hip = np.array([g.aux_model_score for g in groups], np.float64)
+    err = float(np.abs(hip - ref).max())
+    assert err <= TOL
+    if tag == "a":                                             # one predictor call per arrival batch, like the reference's run
+        assert ranker.stats["aux_calls"] == len(z["a_aux_calls"]) and ranker.stats["requests_scored"] == 256
+    n_pairs = n_adj = n_disc = n_steps_diff = 0
+    worst = 0.0
+    for step, got in enumerate(orders):
+        want = z[f"{tag}_order"][step]
+        want = want[want >= 0].tolist()
+        n = len(want)
+        n_pairs += n * (n - 1) // 2
+        n_adj += max(n - 1, 0)
+        if got == want:
+            continue
+        n_steps_diff += 1
+        # discordant pairs are only meaningful inside one priority class; a pair the two orders rank differently must be
+        # an fp32 near-tie: |reference score gap| <= 2 x the measured score error
+        d = discordant_pairs(want, got, ref)
+        n_disc += len(d)
+        for a, b, gap in d:
+            worst = max(worst, gap)
+            assert gap <= 2 * err, (tag, step, a, b, gap, err)
+    print(f"config 1 run {tag}: END-TO-END order (HIP scores -> HIP sort) vs the reference's order over {len(orders)} steps: "
+          f"{n_disc} discordant pairs of {n_pairs} ({n_steps_diff} steps differ), largest reference-score gap among them "
+          f"{worst:.3e}; max|score error| {err:.3e}; closest pair of reference scores {np.diff(np.sort(ref)).min():.3e}")
+    assert n_disc <= max(1, n_adj // 1000)                     # fewer than 0.1 % of the adjacent pairs

@@ -697,7 +697,8 @@ def test_layernorm_fold_on_and_off_agree(dev, monkeypatch, variant):
         assert np.abs(got - wantk).max() <= 2e-4 * max(1.0, np.abs(wantk).max()), k
 
 
-@pytest.mark.parametrize("family", ["tiny_pre_ln", "tiny_post_ln"])     # the OPT-125m and the OPT-350m (config 5's predictor) block structure
+# tiny_*: the OPT-125m and the OPT-350m block structures; opt350m: config 5's predictor itself at its true shape (2,000 requests)
+@pytest.mark.parametrize("family", ["tiny_pre_ln", "tiny_post_ln", "opt350m"])
 @pytest.mark.parametrize("kind", ["burst", "gamma"])
 def test_config5_ranker_side_trace_replay(dev, kind, family):
     """BASELINE config 5, the ranker's share: a burst (everything at t = 0, benchmarks/burst-*.sh) and a gamma arrival
@@ -708,11 +709,21 @@ def test_config5_ranker_side_trace_replay(dev, kind, family):
     from oracle import rank_step as rs
     from vllm_ltr_amd.plugin import MI355XRanker
     from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
-    spec = getattr(OPTSpec, family)()
-    sc = _scorer(spec, seeded_checkpoint(spec, 4), dev, "f16")
-    ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=150)
-    reqs = synthetic_trace(spec.vocab_size, 400, kind, request_rate=200.0, cv=2.0, seed=1, prompt_median=24.0,
-                           output_median=12.0, max_prompt=140)
+    true_shape = family == "opt350m"
+    spec = OPTSpec.opt_350m() if true_shape else getattr(OPTSpec, family)()
+    ckpt = seeded_checkpoint(spec, 0 if true_shape else 4)
+    sc = _scorer(spec, ckpt, dev, "f16")
+    n_req = 2000 if true_shape else 400
+    if true_shape:       # bench.py --trace --model 350m: 2,048-token / 256-sequence budget, prompts of median 64
+        ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=1024)
+        reqs = synthetic_trace(spec.vocab_size, n_req, kind, request_rate=64.0, cv=1.0, seed=0, prompt_median=64.0,
+                               output_median=24.0)
+        budget = dict(backbone_ms=25.0, max_num_batched_tokens=2048, max_num_seqs=256)
+    else:
+        ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=150)
+        reqs = synthetic_trace(spec.vocab_size, n_req, kind, request_rate=200.0, cv=2.0, seed=1, prompt_median=24.0,
+                               output_median=12.0, max_prompt=140)
+        budget = dict(backbone_ms=5.0, max_num_batched_tokens=256, max_num_seqs=16)
     mirror, state = {}, {}
 
     def before(step, s):
@@ -729,12 +740,19 @@ def test_config5_ranker_side_trace_replay(dev, kind, family):
         rs.age_update([mirror[g.request_id] for g in all_pri], [mirror[g.request_id] for g in all_pri if g.request_id in ran_ids])
         state["promoted"] = state.get("promoted", 0) + sum(m.pri == -1 for m in lit)
 
-    res = replay(ranker, reqs, backbone_ms=5.0, max_num_batched_tokens=256, max_num_seqs=16, before_step=before, on_step=after)
+    res = replay(ranker, reqs, before_step=before, on_step=after, **budget)
     s = summarize(res)
-    print(f"{kind}: {s['steps']} steps, max queue {s['max_queue']}, ranker p50/p95/p99 = {s['ranker_ms_all']['p50']:.3f} / "
+    print(f"{family} {kind}: {s['steps']} steps, max queue {s['max_queue']}, ranker p50/p95/p99 = {s['ranker_ms_all']['p50']:.3f} / "
           f"{s['ranker_ms_all']['p95']:.3f} / {s['ranker_ms_all']['p99']:.3f} ms, ranker share of HOL {s['ranker_share_of_hol']:.3f}")
-    assert s["finished"] == 400 and all(r.aux_model_score is not None for r in reqs)
-    assert ranker.stats["requests_scored"] == 400              # every request scored exactly once
+    assert s["finished"] == n_req and all(r.aux_model_score is not None for r in reqs)
+    assert ranker.stats["requests_scored"] == n_req            # every request scored exactly once
+    if true_shape:       # the scores the replay ran on, against the oracle (first / last arrivals and a few in between)
+        pick = [0, 1, n_req // 3, n_req // 2, n_req - 2, n_req - 1]
+        orc = OracleOPTScorer(spec, ckpt)
+        for i in pick:
+            ids_i = np.asarray(reqs[i].prompt_token_ids, np.int64)
+            want = orc.score(ids_i, np.array([0, len(ids_i)], np.int32))[0]
+            assert abs(reqs[i].aux_model_score - want) <= TOL, (i, reqs[i].aux_model_score, want)
     assert state["promoted"] > 0                               # starvation promotions happened and matched
     if kind == "burst":
         assert s["ranker_ms_with_arrivals"]["n"] == 1          # one cold call for the whole burst

@@ -12,6 +12,7 @@ from oracle.opt_scorer import OracleOPTScorer
 from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
 
 from conftest import GOLDEN
+from util import discordant_pairs
 
 
 def _spec_from(npz) -> OPTSpec:
@@ -210,3 +211,78 @@ def test_reserve_select_matches_reference_calls():
         for k in seen:
             seen[k] += int((g("action") == k).sum())
     assert all(v > 0 for v in seen.values()), seen
+
+
+# ---- BASELINE config 1, run end to end by the reference (oracle/make_config1_golden.py) ----------------------------
+def _config1():
+    return np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
+
+
+def test_config1_oracle_scores_and_end_to_end_order():
+    """The oracle predictor on config 1's whole queue (256 requests, 23,078 tokens) against the scores the reference's
+    own fp32 OPTForSequenceClassification produced INSIDE the reference's own Scheduler run - and the END-TO-END order:
+    every step's order from the oracle's scores + the oracle's sort against the order the reference scheduler saw."""
+    z = _config1()
+    spec = OPTSpec.opt_125m()
+    orc = OracleOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])))
+    ids, cu = z["ids"].astype(np.int64), z["cu_seqlens"]
+    got = orc.score_packed(ids, cu)
+    ref = z["ref_score"]
+    err = float(np.abs(got - ref).max())
+    print(f"config 1: oracle vs reference predictor over 256 requests: max|d| = {err:.3e}")
+    assert err <= 1e-5
+    n_disc = 0
+    for tag in ("a", "b"):
+        starv, period = int(z[f"{tag}_starv"]), int(z[f"{tag}_period"])
+        reqs = {i: rs.Req(str(i), float(got[i])) for i in range(len(ref))}
+        for step in range(z[f"{tag}_order"].shape[0]):
+            concat = z[f"{tag}_concat"][step]; concat = concat[concat >= 0]
+            want = z[f"{tag}_order"][step]; want = want[want >= 0]
+            order = [int(r.request_id) for r in rs.opt_order([reqs[int(i)] for i in concat], starv, period)]
+            d = discordant_pairs(want, order, ref)
+            n_disc += len(d)
+            assert all(gap <= 2 * err for _, _, gap in d), (tag, step, d[:3])
+            # keep the counters on the reference's trajectory for the next step (the ran set is the reference's)
+            alive = [reqs[int(i)] for i in np.nonzero(z[f"{tag}_ran"][step] | (np.isin(np.arange(len(ref)), concat)))[0]]
+            rs.age_update(alive, [reqs[int(i)] for i in np.nonzero(z[f"{tag}_ran"][step])[0]])
+            st = z[f"{tag}_states"][step]
+            assert all((r.pri, r.idle, r.runs) == tuple(st[int(r.request_id)]) for r in alive), (tag, step)
+    print(f"config 1: {n_disc} discordant pairs between the oracle's end-to-end order and the reference's over both runs")
+
+
+def test_config1_literal_sort_on_reference_scores_is_bit_identical():
+    z = _config1()
+    ref = z["ref_score"]
+    for tag in ("a", "b"):
+        starv, period = int(z[f"{tag}_starv"]), int(z[f"{tag}_period"])
+        reqs = {i: rs.Req(str(i), float(ref[i])) for i in range(len(ref))}
+        promoted = 0
+        for step in range(z[f"{tag}_order"].shape[0]):
+            concat = z[f"{tag}_concat"][step]; concat = concat[concat >= 0]
+            want = z[f"{tag}_order"][step]; want = want[want >= 0]
+            order = rs.opt_order([reqs[int(i)] for i in concat], starv, period)
+            assert [int(r.request_id) for r in order] == want.tolist(), (tag, step)
+            promoted += sum(r.pri == -1 for r in order)
+            rs.age_update([reqs[int(i)] for i in concat], [reqs[int(i)] for i in np.nonzero(z[f"{tag}_ran"][step])[0]])
+            st = z[f"{tag}_states"][step]
+            assert all((reqs[int(i)].pri, reqs[int(i)].idle, reqs[int(i)].runs) == tuple(st[int(i)]) for i in concat), (tag, step)
+        assert (promoted > 0) == (tag == "b")
+
+
+def test_install_surface_exists_on_the_reference_scheduler():
+    """Every attribute MI355XRanker.install() / the wrapped _schedule touch was found on the reference's real Scheduler
+    object (recorded by oracle/make_config1_golden.py run c, which also checked that the product wiring reproduces the
+    reference's own run step for step)."""
+    import inspect
+    import re
+    from vllm_ltr_amd.plugin import MI355XRanker
+    surf = json.loads(str(_config1()["surface"]))
+    attrs = surf["attributes"]
+    src = inspect.getsource(MI355XRanker.install) + inspect.getsource(MI355XRanker.ordered_requests)
+    touched = set(re.findall(r"scheduler\.(\w+)", src)) - {"py"}      # ("scheduler.py:NNN" citations in comments)
+    assigned_by_engine = {"aux_model", "distribution"}        # llm_engine.py:228-242; scheduler.py:312 (xpt only)
+    assert touched - assigned_by_engine <= set(attrs), touched - set(attrs)
+    assert attrs["_schedule"] == attrs["_general_schedule"] == "method" and attrs["waiting"] == "deque"
+    assert attrs["scheduled_seq_groups[i].seq_group"] == "SequenceGroup"
+    # the wiring's call pattern on the real scheduler: [score the arrivals,] order, age - once per step
+    assert surf["calls"][:3] == [["obtain_aux_scores", 64], ["order", 64], ["age", 64, surf["calls"][2][2]]]

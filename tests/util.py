@@ -33,6 +33,20 @@ def bench_lengths(n, seed=0, mu=64.0):
     return np.clip(np.rint(np.exp(rs.normal(np.log(mu), 0.8, n))), 4, 1024).astype(np.int64)
 
 
+def discordant_pairs(order_ref, order_got, score_of):
+    """Pairs of requests the two orders rank differently (Kendall distance), as (a, b, |score_of[a] - score_of[b]|)."""
+    pos = {int(r): i for i, r in enumerate(order_got)}
+    ref = [int(r) for r in order_ref]
+    assert sorted(pos) == sorted(ref)
+    out = []
+    for i in range(len(ref)):
+        pi = pos[ref[i]]
+        for j in range(i + 1, len(ref)):
+            if pos[ref[j]] < pi:
+                out.append((ref[i], ref[j], abs(float(score_of[ref[i]]) - float(score_of[ref[j]]))))
+    return out
+
+
 class FakeSeqGroup:
     """The SequenceGroup fields the ranking path touches (vllm/sequence.py:426-465,
     vllm/core/scheduler.py:372-374)."""
