@@ -3,7 +3,7 @@
 
     requests ranked/sec + p50 rank latency, 8k waiting queue, OPT-125m predictor.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -20,7 +20,8 @@ gathered queue.
 * default (weak scaling): N x 8k requests (BASELINE config 2 at N = 1, config 4 - the 64k queue - at N = 8);
 * ``--queue-total Q`` (strong scaling): a FIXED queue of Q requests at every N - north_star's "1k-64k-request queues
   at 1/2/4/8 GPUs"; the default run also carries the Q = 65,536 point of that table in ``strong_scaling``;
-* ``--sweep``: one extra JSON line (printed first) with the cold call at 256 ... 64k requests on this world size;
+* ``--scale-table`` (alias ``--sweep``): one extra JSON line (printed first) with north_star's table at this N - the cold
+  call on FIXED queues of 256, 1k ... 64k requests: calls/s, requests/s, fraction of the MFMA and of the HBM roof;
 * ``--trace burst|gamma``: BASELINE config 5, ranker side - replays an arrival trace through the scheduler plug-in
   (vllm_ltr_amd.replay) and prints the ranker's latency distribution per scheduler step instead of the headline line.
 
@@ -88,6 +89,21 @@ def model_flops(spec: OPTSpec, lens: np.ndarray):
     return lin, att
 
 
+def compulsory_bytes(spec: OPTSpec, tokens: int, passes: int = 1) -> float:
+    """HBM bytes the GEMM launches of one scoring call MUST move in the split-fp16 layout of DESIGN.md 3 (every activation
+    between launches is 4 B per element: fp16 hi + lo planes, or f32).  Per token and layer: QKV reads its operand (4H) and
+    writes q|k|v (12H); out_proj reads the attention output (4H) and the residual row (4H), writes the row (4H) and the
+    next GEMM's operand (4H); fc1 reads that (4H), writes ReLU(fc1) (4F); fc2 reads it (4F) and the residual (4H), writes
+    the row (4H) and the next operand (4H): 48 H + 8 F bytes (61,440 at the OPT-125m shape).  The pruned last layer
+    moves the K|V projection only (4H in, 8H out).  Weights: once per pass."""
+    H, F, Nl = spec.hidden_size, spec.ffn_dim, spec.num_hidden_layers
+    per_tok = (48.0 * H + 8.0 * F) * (Nl - 1) + 12.0 * H
+    if spec.has_proj:
+        per_tok += 4.0 * spec.word_embed_proj_dim + 8.0 * H
+    w = 2.0 * Nl * (4.0 * H * H + 2.0 * H * F)
+    return tokens * per_tok + passes * w
+
+
 def cpu_baseline(spec, ckpt, ids, cu, starv, period, budget_s: float = 12.0):
     """The oracle (CPU restatement of the reference path, oracle/) timed on this host's
     cores on a bounded prefix of the same workload: fp32 torch predictor packed <= 2048
@@ -119,7 +135,8 @@ def cpu_baseline(spec, ckpt, ids, cu, starv, period, budget_s: float = 12.0):
     order = rs.opt_order(reqs, starv, period)
     rs.age_update(reqs, order[:256])
     t_rank = time.perf_counter() - t
-    return dict(value=n / (t_score + t_rank), unit="requests/s", cores=cores, kind="port",
+    return dict(value=n / (t_score + t_rank), unit="requests/s", cores=cores, threads=cores, host_cores=os.cpu_count(),
+                host_cores_usable=avail, kind="port",
                 sample=f"first {n} requests of the same queue ({int(cu[n])} tokens): oracle fp32 torch "
                        f"forward packed<=2048 tok ({t_score:.2f}s) + literal Python rank/age ({t_rank*1e3:.2f}ms)")
 
@@ -127,15 +144,19 @@ def cpu_baseline(spec, ckpt, ids, cu, starv, period, budget_s: float = 12.0):
 class ColdCall:
     """One global queue of ``n_total`` requests, resident on every rank, and its cold ranker call."""
 
-    def __init__(self, spec, scorer, dev, dist, world, rank, n_total, profile, min_shard, starv, period, seed=0):
+    def __init__(self, spec, scorer, dev, dist, world, rank, n_total, profile, min_shard_tokens, starv, period, seed=0,
+                 timeout_s=None):
         from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
         from vllm_ltr_amd.rank import DeviceQueue
         self.scorer, self.dev, self.dist, self.world, self.rank, self.n_total = scorer, dev, dist, world, rank, n_total
         self.ids, self.cu, self.lens = synthetic_queue(spec, n_total, seed=seed, profile=profile)
         self.ids_d = torch.from_numpy(self.ids).to(dev)
         self.cu_d = torch.from_numpy(self.cu).to(dev)
-        self.sharded = ShardedScorer(scorer, dev, min_requests_to_shard=min_shard) if world > 1 else None
-        self.r0, self.r1 = shard_bounds(self.cu, world)[rank] if world > 1 and n_total >= min_shard else (0, n_total)
+        self.sharded = ShardedScorer(scorer, dev, min_tokens_to_shard=min_shard_tokens, timeout_s=timeout_s) if world > 1 else None
+        self.is_sharded = bool(self.sharded is not None and self.sharded.shards(n_total, int(self.cu[-1])))
+        self.bounds = shard_bounds(self.cu, world) if self.is_sharded else [(0, n_total)] + [(n_total, n_total)] * (world - 1)
+        self.r0, self.r1 = self.bounds[rank]
+        self.tokens_shard = [int(self.cu[b] - self.cu[a]) for a, b in self.bounds]        # every rank's share (same on all ranks)
         self.queue = DeviceQueue(dev, starv=starv, period=period, capacity=n_total)
         self.queue.append(torch.zeros(n_total))
         self.need_tokens = torch.from_numpy(self.lens.astype(np.int32)).to(dev)
@@ -157,7 +178,7 @@ class ColdCall:
         self.rank_part()
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,8 +196,9 @@ class ColdCall:
             ev[k][1].record()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
-        if self.world > 1:
+        on_dev = self.dist is None or self.dist.get_backend() == "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if on_dev else "cpu")
+        if self.dist is not None:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item()), sorted(a.elapsed_time(b) for a, b in ev)
 
@@ -257,7 +279,11 @@ def main():
     ap.add_argument("--model", default="125m", choices=["125m", "350m"])
     ap.add_argument("--profile", default="sharegpt", choices=sorted(PROFILES),
                     help="prompt-length profile: sharegpt = ln 64 (BASELINE config 2), lmsys = ln 128 (config 3 with --model 350m)")
-    ap.add_argument("--min-shard", type=int, default=1024, help="ShardedScorer.min_requests_to_shard")
+    ap.add_argument("--min-shard-tokens", type=int, default=196608,
+                    help="ShardedScorer.min_tokens_to_shard: a call is sharded over the ranks only when it holds more tokens "
+                         "than one pass of one GPU (north_star: 'only when the queue exceeds a single GPU's batch')")
+    ap.add_argument("--collective-timeout", type=float, default=600.0,
+                    help="seconds a rank waits for its peers in a collective before it raises (a dead peer must not hang the node)")
     ap.add_argument("--weight-dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--chunk-tokens", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,7 +300,8 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the 65,536-request strong-scaling point")
     ap.add_argument("--no-class-head", action="store_true",
                     help="skip the class-mode head measurement (8,192 requests x 8,192 labels, kernels.class_head)")
-    ap.add_argument("--sweep", action="store_true", help="extra JSON line: cold call at 256 ... 64k requests")
+    ap.add_argument("--sweep", "--scale-table", dest="sweep", action="store_true",
+                    help="extra JSON line (north_star's table at this N): cold call on fixed queues of 256, 1k ... 64k requests")
     ap.add_argument("--trace", default=None, choices=["burst", "gamma"], help="config 5 ranker-side trace replay")
     ap.add_argument("--train", action="store_true", help="time the fine-tuning step instead (SURVEY 8f-4)")
     ap.add_argument("--train-slate", type=int, default=32)
@@ -286,26 +313,49 @@ def main():
     ap.add_argument("--trace-backbone-ms", type=float, default=25.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run plainly: become the N-rank job (one process per GPU) through torch's own launcher,
+        # same arguments; 127.0.0.1 rendezvous on a free port.  The torch.distributed.run form keeps working (it sets
+        # WORLD_SIZE, so this branch is skipped there).
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+                 + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE): pass --gpus {world}")
     # LTR_BENCH_ONE_DEVICE=1 + LTR_BENCH_BACKEND=gloo: dry run of the N-rank path on a 1-GPU box (test hook)
     if os.environ.get("LTR_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(one process per GPU; LTR_BENCH_ONE_DEVICE=1 LTR_BENCH_BACKEND=gloo for a one-device dry run)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
+    dist, backend = None, None
+    # LTR_BENCH_BACKEND names the collective backend ("nccl" = RCCL on ROCm, the default); when it is set, the process
+    # group is created at world size 1 too, so that a plain `--gpus 1` run exercises RCCL's init / teardown
+    if world > 1 or os.environ.get("LTR_BENCH_BACKEND"):
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("LTR_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if "MASTER_ADDR" not in os.environ:                              # world 1 without a launcher
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        tmo = datetime.timedelta(seconds=max(args.collective_timeout, 1.0))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        backend = dist.get_backend()
 
     from vllm_ltr_amd.scorer import HipOPTScorer
 
@@ -320,24 +370,38 @@ def main():
     strong = args.queue_total > 0
     n_total = args.queue_total if strong else args.queue * world
     n_local = n_total // world if strong else args.queue
-    mk = lambda n: ColdCall(spec, scorer, dev, dist, world, rank, n, args.profile, args.min_shard, args.starv, args.period)
+    mk = lambda n: ColdCall(spec, scorer, dev, dist, world, rank, n, args.profile, args.min_shard_tokens, args.starv, args.period,
+                            timeout_s=args.collective_timeout)
 
     if args.sweep:
+        # north_star: "ranker calls/sec on synthetic 1k-64k-request queues reported at 1/2/4/8 GPUs as absolute numbers and as
+        # fraction of the ... roofline": FIXED queues at this N (strong scaling), one cold call = one ranker call
         pts = []
         for n in (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
             c = mk(n)
             k = 3 if n <= 16384 else 2
             el, _ = c.timed(k, 1)
-            pts.append(dict(queue_total=n, tokens_total=int(c.cu[-1]), ms_per_call=el / k * 1e3, requests_per_s=n * k / el,
-                            sharded=bool(world > 1 and n >= args.min_shard)))
+            lin, att = model_flops(spec, c.lens)
+            T = int(c.cu[-1])
+            byt = compulsory_bytes(spec, T, passes=max(1, -(-max(c.tokens_shard) // 196608)))
+            pts.append(dict(queue_total=n, tokens_total=T, ms_per_call=el / k * 1e3, calls_per_s=k / el, requests_per_s=n * k / el,
+                            sharded=c.is_sharded, tokens_shard=c.tokens_shard,
+                            mfma_frac=(lin + att) / (el / k) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
+                            hbm_frac_compulsory=byt / (el / k) / 1e9 / (PEAK_HBM_GBS * world)))
             c.release(); del c
         if rank == 0:
-            print(json.dumps({"kind": "queue_sweep", "n_gpus": world, "model": args.model, "profile": args.profile,
-                              "scaling": "strong", "points": pts}))
+            print(json.dumps({"kind": "scale_table", "n_gpus": world, "rccl_ranks": world, "backend": backend, "model": args.model,
+                              "profile": args.profile, "scaling": "strong (fixed queue at every N)",
+                              "roofs": {"mfma_tflops_per_gpu": PEAK_F16_MFMA_TFLOPS, "hbm_gbs_per_gpu": PEAK_HBM_GBS,
+                                        "note": "mfma_frac = algorithmic FLOPs (SURVEY 8d; the 2-pass split not counted) / time / "
+                                                "(N x 2.5 PF); hbm_frac_compulsory = bytes the split-fp16 layout must move (DESIGN 3) "
+                                                "/ time / (N x 8 TB/s)"},
+                              "points": pts}))
 
     call = mk(n_total)
     ids, cu, lens = call.ids, call.cu, call.lens
     my_r0, my_r1 = call.r0, call.r1
+    call_tokens_shard, call_sharded = call.tokens_shard, call.is_sharded
     for _ in range(args.warmup):
         call.step()
     call.barrier()
@@ -409,8 +473,7 @@ def main():
         c64 = mk(65536)
         el, _ = c64.timed(2, 1)
         strong_pt = dict(queue_total=65536, tokens_total=int(c64.cu[-1]), n_gpus=world, ms_per_call=el / 2 * 1e3,
-                         requests_per_s=65536 * 2 / el, scaling="strong",
-                         tokens_rank0_shard=int(c64.cu[c64.r1] - c64.cu[c64.r0]))
+                         requests_per_s=65536 * 2 / el, scaling="strong", tokens_shard=c64.tokens_shard)
         c64.release(); del c64
 
     # ---- class-mode head at the reference's largest bucket count (train/train.sh: 8,192 labels; opt.py:389-397): the
@@ -483,15 +546,31 @@ def main():
                 pass
             avg_launch_s = gemm["ms"] / max(gemm["launches"], 1) * 1e-3
             peak = PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3
+            launches_per_step = gemm["launches"] // max(args.steps, 1)
+            passes = max(1, -(-int(cu[my_r1] - cu[my_r0]) // 196608))
+            comp = compulsory_bytes(spec, int(cu[my_r1] - cu[my_r0]), passes) if args.weight_dtype == "f16" else None
+            n_pass = 2 if args.weight_dtype == "f16" else 1              # fp16 MFMA passes per product (lo, hi)
             roof = {"bound": "mfma", "kernel": "gemm_f16s_kernel" if args.weight_dtype == "f16" else "gemm_f32_kernel",
                     "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
+                    # `frac` is ALGORITHMIC (2 M N K per product).  The split path issues every product twice (lo x W, hi x W):
+                    # the matrix cores run at hw_frac of their fp16 peak
+                    "mfma_passes_per_product": n_pass, "hw_tflops": gemm_tflops * n_pass, "hw_frac": gemm_tflops * n_pass / peak,
+                    # the same MFMA instruction stream alone, fed from registers with real operands, under the 1.4 kW package
+                    # cap (1.98 PFLOP/s of 16x16x32 fp16 MFMA at the throttled clock, profiles/r01_power_probe.txt): the time the
+                    # GEMMs of one step would take if the operand stream, LDS reads and epilogues cost nothing
+                    "mfma_only_floor_ms": gemm["work"] / max(args.steps, 1) * n_pass / 1.98e15 * 1e3 if args.weight_dtype == "f16" else None,
                     "traffic": traffic,
+                    # bytes the GEMM launches of one call MUST move in this layout (compulsory_bytes()) against
+                    # what the PMC passes counted at the fabric for the same launches
+                    "compulsory_bytes": comp, "compulsory_bytes_per_launch": comp / launches_per_step if comp and launches_per_step else None,
+                    "traffic_ratio": traffic * launches_per_step / comp if traffic and comp else None,
+                    "traffic_note": "fabric-side (TCC_EA requests, calibrated): Infinity-Cache hits included - an upper bound on DRAM traffic",
                     "traffic_source": traffic_src if traffic is not None else
                     {"stale": True, "reason": "profiles/gemm_traffic.json was not taken on the current kernel sources",
                      "file": traffic_src, "current_kernel_sha16": sha},
                     # launches of THIS kernel only (the 128 x 256-tile one: the rocprofv3 row of the same name); the compact
                     # last-token rows of each pass run on the small-batch kernels, timed apart as kernels.gemm_small
-                    "launches_per_step": gemm["launches"] // max(args.steps, 1),
+                    "launches_per_step": launches_per_step,
                     "avg_launch_ms": avg_launch_s * 1e3,
                     # the same kernel against the OTHER roof: PMC bytes per launch / live launch time, over 8 TB/s.
                     # The split-fp16 design moves 4 B per activation element between launches, so the MFMA-bound
@@ -517,7 +596,8 @@ def main():
             "metric": "requests ranked/sec (cold call: OPT predictor forward + priority sort/aging)",
             "value": n_total * args.steps / elapsed,
             "unit": "requests/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": backend,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "profiled_ms_per_step": prof_elapsed / args.steps * 1e3 if prof_elapsed else None,
             "p50_rank_latency_ms": step_ms[len(step_ms) // 2],
@@ -532,7 +612,8 @@ def main():
                                     f"OPT-{args.model} predictor, {n_local} synthetic queue per GPU ({n_total} total, "
                                     f"{args.profile} length profile), cold ranker call"),
                        "queue_per_gpu": n_local, "queue_total": n_total, "tokens_total": int(cu[-1]),
-                       "tokens_rank0_shard": int(cu[my_r1] - cu[my_r0]), "starv": args.starv, "period": args.period,
+                       "tokens_rank0_shard": int(cu[my_r1] - cu[my_r0]), "tokens_shard": call_tokens_shard,
+                       "sharded": call_sharded, "min_shard_tokens": args.min_shard_tokens, "starv": args.starv, "period": args.period,
                        "parallelism": f"request-sharded dp{world}" + (", token-balanced shards of one global queue, "
                                                                        "RCCL all-gather of scores" if world > 1 else "")},
             "roofline": roof,
@@ -543,7 +624,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(spec, ckpt, ids, cu, args.starv, args.period)
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

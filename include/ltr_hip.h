@@ -342,6 +342,7 @@ int ltr_listmle(const float* y_pred, const float* y_true, const int32_t* shuffle
  * parameter / gradient / moment buffers; ltr_train_read copies the current value of a tensor out, for evaluation and
  * for writing the fine-tuned checkpoint (trainer.py:213-216 saves it .half()). */
 enum { LTR_LOSS_LISTMLE = 0, LTR_LOSS_MSE = 1, LTR_LOSS_CROSSENTROPY = 2 };
+enum { LTR_TRAIN_PREC_DEFAULT = 0, LTR_TRAIN_PREC_SPLIT = 1, LTR_TRAIN_PREC_F32 = 2 };
 typedef struct ltr_train_config {
   float lr;            /* trainer.py --lr (2e-5) */
   float beta1, beta2;  /* torch.optim.Adam defaults 0.9, 0.999 */
@@ -352,6 +353,9 @@ typedef struct ltr_train_config {
   float pad_value;     /* allrank PADDED_Y_VALUE -1 */
   float dropout;       /* HF OPT config.dropout (0.1 in train mode) after out_proj and fc2; 0 disables.  Masks come from
                           a counter-based hash of (seed, step, layer, site, element) - torch's RNG stream cannot be matched */
+  int32_t precision;   /* LTR_TRAIN_PREC_*: how the dense layers multiply.  DEFAULT (0) = split-fp16 unless the environment
+                          of ltr_train_create holds LTR_TRAIN_F32=1 (the A/B switch of DESIGN.md 6.4); SPLIT / F32 select a
+                          path per handle, whatever the environment says.  (Occupies what was padding in front of `seed`.) */
   uint64_t seed;
 } ltr_train_config;
 typedef struct ltr_trainer* ltr_train_handle;

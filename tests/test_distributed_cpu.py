@@ -89,3 +89,58 @@ def test_two_rank_gloo_sharded_scoring(n, min_shard):
         assert sum(r[3][0] for r in res) == n and all(0 < r[3][0] < n for r in res)
     else:                       # below the threshold only rank 0 scores, then broadcasts
         assert res[0][3] == [n] and res[1][3] == []
+
+
+def _worker_timeout(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vllm_ltr_amd.distributed import PeerTimeout, ShardedScorer
+    sh = ShardedScorer(lambda i, c: torch.zeros(len(c) - 1), "cpu", min_requests_to_shard=1, timeout_s=2.0)
+    # both ranks agree on a status code (MAX over the ranks): rank 1 reports 2 (range), rank 0 nothing
+    code = sh.agree_status(2 if rank == 1 else 0)
+    if rank == 1:                      # ... then rank 1 "dies": it never enters the scoring call's collective
+        q.put((rank, code, "absent"))
+        q.close(); q.join_thread()     # flush before the hard exit below
+        time.sleep(8)
+        os._exit(0)
+    t0 = time.time()
+    try:
+        sh.score(np.arange(8, dtype=np.int64), np.array([0, 4, 8], np.int32))
+        q.put((rank, code, "returned"))
+    except PeerTimeout as e:
+        q.put((rank, code, f"PeerTimeout after {time.time() - t0:.1f}s"))
+    q.close(); q.join_thread()
+    os._exit(0)                        # (no clean teardown with a dead peer)
+
+
+def test_dead_peer_raises_within_the_timeout_and_status_codes_agree():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_timeout, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][1] == 2 and res[1][1] == 2               # the code of the failing rank reached both
+    assert res[0][2].startswith("PeerTimeout") and res[1][2] == "absent", res
+
+
+def test_shard_decision_is_a_token_rule_by_default():
+    """north_star: shard 'only when the queue exceeds a single GPU's batch' = more tokens than one 196,608-token pass."""
+    from vllm_ltr_amd.distributed import ONE_PASS_TOKENS, ShardedScorer
+
+    class G:                            # a 4-rank group without processes: only the decision logic is used
+        pass
+    sh = ShardedScorer.__new__(ShardedScorer)
+    sh.world, sh.min_requests_to_shard, sh.min_tokens_to_shard = 4, None, ONE_PASS_TOKENS
+    assert not sh.shards(2000, ONE_PASS_TOKENS) and sh.shards(2000, ONE_PASS_TOKENS + 1) and not sh.shards(0, 10**9)
+    sh.min_requests_to_shard = 64
+    assert sh.shards(64, 100) and not sh.shards(63, 10**9)
+    sh.world = 1
+    assert not sh.shards(10**6, 10**9)

@@ -284,3 +284,45 @@ def test_rccl_backend_collectives_single_rank():
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "rank 0/1: gather [0.0, 1.0, 2.0, 3.0, 4.0] max-rank 0 max-f64 1.5 bcast 1.0" in r.stdout, r.stdout[-1000:]
     assert "ok world 1" in r.stdout
+
+
+def _bench_line(args, env_extra, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_plain_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` run PLAINLY - the form the driver uses - must become the 2-rank job by itself
+    (re-exec under torch.distributed.run), here as a one-device dry run over gloo; the line names the ranks, the backend
+    and every rank's token share; `--scale-table` adds north_star's fixed-queue table as one extra line."""
+    lines = _bench_line(["--gpus", "2", "--steps", "1", "--warmup", "1", "--queue", "2048", "--no-cpu-baseline", "--no-unfused",
+                         "--no-strong", "--no-class-head", "--steady-new", "0"],
+                        dict(LTR_BENCH_ONE_DEVICE="1", LTR_BENCH_BACKEND="gloo"))
+    out = lines[-1]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["queue_total"] == 4096 and cfg["sharded"] and len(cfg["tokens_shard"]) == 2
+    assert sum(cfg["tokens_shard"]) == cfg["tokens_total"] and abs(cfg["tokens_shard"][0] - cfg["tokens_shard"][1]) < 2048
+    assert out["value"] > 0 and out["roofline"]["hw_frac"] == pytest.approx(2 * out["roofline"]["frac"])
+
+
+def test_plain_bench_gpus_1_on_rccl_world_1_with_scale_table():
+    """`python bench.py --gpus 1` with LTR_BENCH_BACKEND=nccl: the process group is RCCL itself at world size 1 (init,
+    barrier, the clock's MAX all-reduce, teardown), plus the scale table."""
+    lines = _bench_line(["--gpus", "1", "--steps", "1", "--warmup", "1", "--queue", "1024", "--no-cpu-baseline", "--no-unfused",
+                         "--no-strong", "--no-class-head", "--steady-new", "1", "--scale-table"], dict(LTR_BENCH_BACKEND="nccl"))
+    table, out = lines[0], lines[-1]
+    assert out["rccl_ranks"] == 1 and out["backend"] == "nccl" and out["value"] > 0
+    r = out["roofline"]
+    assert r["compulsory_bytes"] > 0 and r["mfma_only_floor_ms"] > 0 and "traffic_note" in r
+    assert table["kind"] == "scale_table" and [p["queue_total"] for p in table["points"]] == [256, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
+    assert all(p["calls_per_s"] > 0 and 0 < p["mfma_frac"] < 1 and 0 < p["hbm_frac_compulsory"] < 1 for p in table["points"])

@@ -76,11 +76,13 @@ def test_config2_opt125m_8k_queue_full_size():
     assert len(passes) == 4
     assert np.isfinite(s4).all()
     assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s4)          # deterministic
+    # how the queue is cut into passes: the token rows run the same kernels at every cut (bit-identical there); the compact
+    # last-token rows of a pass (745 ... 8,192 of them) may change GEMM kernel with the pass size: <= 2e-6
     sc.set_chunk_tokens(65536)                                                          # 11 passes
     assert len(_passes(cu, 65536)) == 11
-    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s4)
+    assert np.abs(sc.score_device(ids_d, cu_d, cu).cpu().numpy() - s4).max() <= 2e-6
     sc.set_chunk_tokens(1 << 20)                                                        # ONE 709k-token pass
-    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s4)
+    assert np.abs(sc.score_device(ids_d, cu_d, cu).cpu().numpy() - s4).max() <= 2e-6
     sc.set_chunk_tokens(0)
     # last-layer pruning (ltr_score carries only the last-token rows through the tail of layer 12) against the
     # unpruned forward of a whole pass, H = 768: pool the full hidden states of pass 2 (non-zero offsets)
@@ -147,14 +149,14 @@ def test_config3_opt350m_8k_lmsys_like_queue_full_size():
     assert len(passes) >= 6 and np.isfinite(s).all()
     assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s)           # deterministic
     sc.set_chunk_tokens(98304)                                                          # twice as many passes
-    assert np.array_equal(sc.score_device(ids_d, cu_d, cu).cpu().numpy(), s)
+    assert np.abs(sc.score_device(ids_d, cu_d, cu).cpu().numpy() - s).max() <= 2e-6
     sc.set_chunk_tokens(0)
     # permutation of the requests: the score of a request does not depend on its neighbours
     perm = np.random.RandomState(2).permutation(8192)
     ids_p = np.concatenate([ids[cu[i]:cu[i + 1]] for i in perm])
     cu_p = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.int32)
     sp = sc.score_device(torch.from_numpy(ids_p).to(dev), torch.from_numpy(cu_p).to(dev), cu_p).cpu().numpy()
-    assert np.array_equal(sp, s[perm])
+    assert np.abs(sp - s[perm]).max() <= 2e-6             # (the passes cut elsewhere: other kernels for their compact rows)
     sample = _sample(passes, 8192, 16, seed=3)
     assert len(sample) >= 28
     want = _oracle_scores(spec, ckpt, ids, cu, sample)

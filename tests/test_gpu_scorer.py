@@ -155,8 +155,9 @@ def test_last_layer_pruning_is_invisible(dev, mk, monkeypatch):
     """ltr_score carries only the last-token rows through the last layer: Q, the attention output, out_proj, the
     LayerNorms and the MLP for n_req rows, K | V for every token; ltr_forward_hidden runs every row.  With the
     last-query attention switched off (LTR_NO_LASTQ=1) only per-token maps are pruned and pooling the full hidden
-    states gives the same scores bit for bit; with it (default) the last query's softmax runs in f32 on the VALU
-    instead of the split-fp16 MFMA passes - f32-grade agreement."""
+    states gives the same scores to f32 rounding (5e-7; round 3: bit for bit, when every batch size ran the same GEMM
+    arithmetic); with it (default) the last query's softmax runs in f32 on the VALU instead of the split-fp16 MFMA
+    passes - f32-grade agreement."""
     spec = mk()
     ckpt = seeded_checkpoint(spec, 6)
     ids, cu = synthetic_batch(spec, [9, 1, 64, 65, 2, 130, 33, 128, 31, 7, 8, 150], 10)
@@ -169,17 +170,17 @@ def test_last_layer_pruning_is_invisible(dev, mk, monkeypatch):
     np.testing.assert_allclose(pruned, full, atol=2e-6, rtol=0)
     monkeypatch.setenv("LTR_NO_LASTQ", "1")
     sc2 = _scorer(spec, ckpt, dev, "f16")
-    if spec.do_layer_norm_before:
-        assert np.array_equal(sc2.score(ids, cu), full)
-    else:
-        # post-LN blocks: the compact rows of the pruned last layer run with explicit LayerNorm launches, the full
-        # forward rebuilds the LayerNorm'd residuals in the GEMM epilogues (LayerNorm fold): same maths, different
-        # rounding - f32-grade agreement instead of bit identity
-        np.testing.assert_allclose(sc2.score(ids, cu), full, atol=5e-7, rtol=0)
+    # the same maths with different rounding - f32-grade agreement, not bit identity: the compact rows of the pruned last
+    # layer (12 rows) and the full forward (700 rows) pick different GEMM kernels / split-K (launch_gemm chooses per launch),
+    # and for post-LN blocks the compact rows run with explicit LayerNorm launches where the full forward rebuilds the
+    # LayerNorm'd residuals in the GEMM epilogues
+    np.testing.assert_allclose(sc2.score(ids, cu), full, atol=5e-7, rtol=0)
 
 
 def test_chunking_is_invisible(dev):
-    """Scores do not depend on how the batch is cut into passes."""
+    """Scores do not depend on how the batch is cut into passes - beyond the 2e-6 by which a score may move
+    between the GEMM kernels the pass size selects (small passes run the narrow outputs with split-K: another summation
+    order; tests/test_gpu_small_batches.py) - and a given cut is deterministic."""
     spec = OPTSpec.tiny_pre_ln()
     ckpt = seeded_checkpoint(spec, 8)
     lens = bench_lengths(300, seed=1, mu=24.0).clip(1, 150)
@@ -188,7 +189,8 @@ def test_chunking_is_invisible(dev):
     whole = sc.score(ids, cu)
     sc.set_chunk_tokens(200)          # many request-aligned chunks
     parts = sc.score(ids, cu)
-    assert np.array_equal(whole, parts)
+    assert np.array_equal(parts, sc.score(ids, cu))
+    assert np.abs(whole - parts).max() <= 2e-6 * max(1.0, float(np.abs(whole).max()))
     orc = OracleOPTScorer(spec, ckpt)
     assert np.abs(whole - orc.score(ids, cu)).max() <= TOL
 
@@ -753,7 +755,8 @@ def test_config5_ranker_side_trace_replay(dev, kind, family):
             ids_i = np.asarray(reqs[i].prompt_token_ids, np.int64)
             want = orc.score(ids_i, np.array([0, len(ids_i)], np.int32))[0]
             assert abs(reqs[i].aux_model_score - want) <= TOL, (i, reqs[i].aux_model_score, want)
-    assert state["promoted"] > 0                               # starvation promotions happened and matched
+    if not (true_shape and kind == "gamma"):                   # (64 req/s against a 256-sequence budget never starves a request)
+        assert state["promoted"] > 0                           # starvation promotions happened and matched
     if kind == "burst":
         assert s["ranker_ms_with_arrivals"]["n"] == 1          # one cold call for the whole burst
     else:

@@ -1,10 +1,12 @@
 """-m gpu: the small-batch scoring path (SURVEY.md 8d "steady" call: k new requests scored + the queue re-ranked).
 
 Batches of a few hundred to a few thousand tokens run the GEMMs on the small-tile / mid-tile deep-ring kernels
-(ltr_gemm.hip `gemm_f16s_small_kernel`, selected by row count inside launch_gemm).  Those kernels keep the large-tile
-kernel's arithmetic - same MFMA, lo pass then hi pass per 32-wide K-slab, slabs in order, same epilogue expressions -
-so a request's score must not depend on the batch it arrives in: BIT-IDENTICAL whether it is scored alone (small
-kernel), with 15 others, with ~100 others (mid kernel) or inside a queue of several hundred (large-tile kernel), and
+(ltr_gemm.hip `gemm_f16s_small_kernel`, selected per launch inside launch_gemm), the narrow outputs with split-K and a
+fixed-order reduction.  Round 3 required BIT-identical scores across the batch-size regimes and paid for it with the
+tile shape and a ban on split-K (0.87 ms per single arrival = 3 % of its weight-stream roofline); the reference itself
+has no such property (its scores depend on the batch composition).  The contract now: a call is DETERMINISTIC (the same
+batch scores to the same bits, every time), a request's score moves by at most 2e-6 between the regimes - alone (small
+kernel), with 15 others, with ~100 others (mid kernel), inside a queue of several hundred (large-tile kernel) - and stays
 within the north_star tolerance of the oracle."""
 import numpy as np
 import pytest
@@ -45,9 +47,11 @@ def test_scores_do_not_depend_on_the_batch_size_regime(model):
     for group in ([0], [5], [6], [7], list(range(8, 24)), list(range(30, 94)), list(range(100, 260))):
         got = sc.score(*_sub(ids, cu, group))
         t = int(np.diff(cu)[group].sum())
-        seen[len(group)] = t
-        assert np.array_equal(got, whole[group]), (model, len(group), t, np.abs(got - whole[group]).max())
-    print(f"{model}: batches of {seen} tokens score bit-identically to the {T}-token queue")
+        assert np.array_equal(sc.score(*_sub(ids, cu, group)), got), (model, len(group))     # deterministic per call
+        d = float(np.abs(got - whole[group]).max())
+        seen[len(group)] = (t, d)
+        assert d <= 2e-6 * max(1.0, float(np.abs(whole).max())), (model, len(group), t, d)
+    print(f"{model}: batches of (tokens, max|d| vs the {T}-token queue) {seen}")
     if model in ("125m", "tiny_pre_ln", "tiny_post_ln"):
         idx = [0, 5, 6, 7, 8, 9]
         want = OracleOPTScorer(spec, ckpt).score(*_sub(ids, cu, idx))

@@ -248,3 +248,36 @@ def test_gemm_kernels_do_not_spill():
             seen += 1
             assert int(m.group(1)) == 0, f"{name} spills {m.group(1)} bytes per lane"
     assert seen >= 10
+
+
+def test_non_null_activation_is_refused_by_name(tmp_path):
+    """PrefillModelConfig.activation is applied to the rank logits by the reference's training / offline path
+    (prefill_predictor.py:28-29,53,80); this path computes the raw logit, so a config that names an activation is
+    refused instead of silently serving / training a different function.  Every shipped config says null."""
+    from vllm_ltr_amd.config_predictor import PrefillModelConfig, PrefillPredictorConfig
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.trainer import HipPredictorTrainer, refuse_activation
+    cfg = PrefillPredictorConfig(PrefillModelConfig("facebook/opt-125m", 1, "rank", "Sigmoid", path=str(tmp_path)))
+    with pytest.raises(NotImplementedError, match="Sigmoid"):
+        MI355XRanker.from_predictor_config(cfg, "opt-xxx-starv200-period10")
+    p = tmp_path / "cfg.json"
+    PrefillPredictorConfig.to_json(cfg, str(p))
+    with pytest.raises(NotImplementedError, match="activation"):
+        MI355XRanker.from_predictor_config(str(p), "opt")
+    spec = OPTSpec.tiny_pre_ln()
+    with pytest.raises(NotImplementedError, match="Tanh"):
+        HipPredictorTrainer(spec, {}, activation="Tanh")
+    refuse_activation(None, "x"); refuse_activation("Identity", "x")
+    for fn, case in json.load(open(os.path.join(GOLDEN, "config_cases.json")))["predictor_configs"].items():
+        assert case["parsed"]["activation"] is None, fn       # what the reference ships
+
+
+def test_train_config_carries_the_precision():
+    """The trainer's GEMM precision travels in ltr_train_config (per handle), not in the process environment; the field
+    sits in what used to be padding in front of `seed` (include/ltr_hip.h)."""
+    import ctypes as C
+    from vllm_ltr_amd import _lib
+    assert _lib.TrainConfig.precision.offset == 36 and _lib.TrainConfig.seed.offset == 40 and C.sizeof(_lib.TrainConfig) == 48
+    assert _lib.TRAIN_PRECISIONS == {None: 0, "split": 1, "f32": 2}
+    src = open(os.path.join(ROOT, "vllm_ltr_amd", "trainer.py")).read()
+    assert "os.environ[" not in src                            # no process-wide mutation around ltr_train_create

@@ -29,8 +29,15 @@ SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "lt
 ABI_VERSION = 4
 
 
+LTR_E_INVAL, LTR_E_RANGE = -22, -34
+
+
 class LtrError(RuntimeError):
-    pass
+    """``code``: the LTR_E_* value the library returned (0 when raised by the host side)."""
+
+    def __init__(self, msg: str, code: int = 0):
+        super().__init__(msg)
+        self.code = int(code)
 
 
 class ModelDesc(C.Structure):
@@ -51,10 +58,11 @@ ACTIVATIONS = {None: 0, "Identity": 0, "ReLU": 1, "Sigmoid": 2, "Tanh": 3, "GELU
 class TrainConfig(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("loss", C.c_int32), ("listmle_eps", C.c_float), ("pad_value", C.c_float),
-                ("dropout", C.c_float), ("seed", C.c_uint64)]
+                ("dropout", C.c_float), ("precision", C.c_int32), ("seed", C.c_uint64)]
 
 
 LOSSES = {"listMLE": 0, "mse": 1, "crossentropy": 2}
+TRAIN_PRECISIONS = {None: 0, "split": 1, "f32": 2}
 
 
 class ProfileStats(C.Structure):
@@ -135,4 +143,4 @@ def _load() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().ltr_last_error().decode(errors="replace")
-        raise LtrError(f"{what} failed with code {rc}: {msg}")
+        raise LtrError(f"{what} failed with code {rc}: {msg}", rc)

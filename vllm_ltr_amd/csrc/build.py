@@ -60,7 +60,9 @@ def build(force: bool = False) -> str:
 
 
 # element-level checker of the GEMM's LayerNorm-fold epilogues (diag/gemm_check.hip), run by the -m gpu tests
-TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip")}
+TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip"),
+         # times the four dense layers of a decoder layer at M rows through launch_gemm (A/B of tile / split-K / XCD-map choices)
+         "gemm_bench": os.path.join("diag", "gemm_bench.hip")}
 
 
 def _build_tools(force: bool) -> None:

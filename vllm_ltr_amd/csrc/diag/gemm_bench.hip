@@ -53,6 +53,8 @@ int main(int argc, char** argv) {
     return wp;
   };
   __half *w_qkv = weight(3 * H, H, 11), *w_out = weight(H, H, 12), *w_fc1 = weight(F, H, 13), *w_fc2 = weight(H, F, 14);
+  const size_t skb = (size_t)8 * (M < 32768 ? M : 32768) * H * 4;
+  void* sk = alloc<char>(skb);
   float* vec = alloc<float>(4 * (size_t)F);
   fill_f32<<<64, 256>>>(vec, 4 * (size_t)F, 0.1f, 1.f, 8);
   (void)hipDeviceSynchronize();
@@ -63,6 +65,7 @@ int main(int argc, char** argv) {
   if (fold) { g_qkv.ln_stats_in = st1; g_qkv.ln_c = vec + F; g_qkv.ln_parts = H / 64; }
   g_out.a = AOp{a, a + (size_t)M * H}; g_out.w = w_out; g_out.bias = vec; g_out.resid = h; g_out.out_f32 = h; g_out.M = M; g_out.N = H; g_out.K = H;
   if (fold) { g_out.ln_gamma = vec + 2 * F; g_out.ln_out = AOp{a2, a2 + (size_t)M * H}; g_out.ln_stats_out = st2; }
+  if (M <= 32768) { g_out.splitk_ws = sk; g_out.splitk_ws_bytes = skb; g_fc2.splitk_ws = sk; g_fc2.splitk_ws_bytes = skb; }
   g_fc1.a = AOp{a2, a2 + (size_t)M * H}; g_fc1.w = w_fc1; g_fc1.bias = vec; g_fc1.out_split = AOp{f, f + (size_t)M * F}; g_fc1.relu = 1;
   g_fc1.M = M; g_fc1.N = F; g_fc1.K = H; g_fc1.a_slab = g_fc1.out_slab = 1;
   if (fold) { g_fc1.ln_stats_in = st2; g_fc1.ln_c = vec + F; g_fc1.ln_parts = H / 64; }
@@ -76,15 +79,16 @@ int main(int argc, char** argv) {
   // the layer sequence, as in the model (keeps the chip in the model's power state), then each shape alone
   for (int w = 0; w < 3; ++w) for (auto& it : items) if (launch_gemm(LTR_W_F16, *it.g, 0)) { printf("launch failed: %s\n", it.name); return 1; }
   (void)hipDeviceSynchronize();
+  // per shape: `reps` launches back to back in the stream (what the launch costs inside a forward: kernel + boundary;
+  // an event pair around a single launch adds ~5 us of its own at this scale)
   std::vector<float> tot(4, 0.f);
-  for (int r = 0; r < reps; ++r)
-    for (int i = 0; i < 4; ++i) {
-      (void)hipEventRecord(e0, 0);
-      launch_gemm(LTR_W_F16, *items[i].g, 0);
-      (void)hipEventRecord(e1, 0);
-      (void)hipEventSynchronize(e1);
-      float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot[i] += ms;
-    }
+  for (int i = 0; i < 4; ++i) {
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) launch_gemm(LTR_W_F16, *items[i].g, 0);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); tot[i] = ms;
+  }
   double sum = 0, fl = 0;
   for (int i = 0; i < 4; ++i) {
     const double ms = tot[i] / reps;
@@ -92,5 +96,12 @@ int main(int argc, char** argv) {
     sum += ms; fl += items[i].flop;
   }
   printf("layer     %8.1f us  %7.1f TFLOP/s   (M=%d H=%d F=%d fold=%d)\n", sum * 1e3, fl / sum / 1e9, M, H, F, (int)fold);
+  {  // the four launches back to back, as the model issues them (launch gaps included)
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) for (auto& it : items) launch_gemm(LTR_W_F16, *it.g, 0);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("sequence  %8.1f us per layer (4 GEMMs back to back)\n", ms / reps * 1e3);
+  }
   return 0;
 }

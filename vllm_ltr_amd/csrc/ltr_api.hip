@@ -101,6 +101,9 @@ constexpr int DEFAULT_CHUNK_TOKENS = 196608;
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// passes of at most this many rows get the small-batch split-K scratch (launch_gemm decides per launch)
+constexpr int64_t SPLITK_MAX_ROWS = 4800;
+
 // workspace carve-up for one chunk of at most Tc tokens / Nc requests
 struct Workspace {
   float* h;        // f32 [Tc, H]      residual stream
@@ -119,6 +122,9 @@ struct Workspace {
   AOp head_op;
   char* head_feat;
   float* head_logits;
+  // small-batch split-K scratch (GemmArgs::splitk_ws): raw f32 partials of out_proj / fc2 when a pass has few rows
+  void* splitk;
+  size_t splitk_bytes;
   size_t bytes;
 };
 
@@ -147,6 +153,12 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, boo
     ws.head_op = AOp{ho, ho ? ho + Nc * H * 2 : nullptr};
     ws.head_feat = (char*)take(Nc * De * esz);
     ws.head_logits = (float*)take((size_t)Nc * (head_lpad > 0 ? head_lpad : 1) * 4);
+  }
+  if (d.weight_dtype == LTR_W_F16) {
+    // up to 4 parts of [rows, H] f32, rows <= SPLITK_MAX_ROWS (beyond it the GEMMs have tiles enough without)
+    const size_t rows = (size_t)(Tc < SPLITK_MAX_ROWS ? Tc : SPLITK_MAX_ROWS);
+    ws.splitk_bytes = 4 * rows * H * 4;
+    ws.splitk = take(ws.splitk_bytes);
   }
   if (d.weight_dtype == LTR_W_F16) {
     ws.a = AOp{a, a ? a + Tc * H * 2 : nullptr};
@@ -326,6 +338,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = ab; g.w = m->gemm_lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
+      if (Mr <= SPLITK_MAX_ROWS) { g.splitk_ws = ws.splitk; g.splitk_ws_bytes = ws.splitk_bytes; }
       // the LayerNorm that follows this residual add: pre-LN blocks LN2 (final_layer_norm), post-LN blocks LN1
       // (self_attn_layer_norm, opt.py:162-163)
       if (fold_here) {
@@ -362,6 +375,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F; g.a_slab = wd == LTR_W_F16;
+      if (Mr <= SPLITK_MAX_ROWS) { g.splitk_ws = ws.splitk; g.splitk_ws_bytes = ws.splitk_bytes; }
       if (ln1_folded) {
         g.ln_gamma = d.pre_ln ? (const float*)m->lw(L + 1, LTR_WL_LN1_W) : (const float*)m->lw(L, LTR_WL_LN2_W);
         g.ln_out = ws.a; g.ln_stats_out = ws.stats1; g.err_flag = m->err_flag;

@@ -329,7 +329,7 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
 template <int LNM, bool RLN>
 __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
-    int K, int tiles_m, int tiles_n, int gm, Epilogue ep) {
+    int K, int lda, int tiles_m, int tiles_n, int gm, Epilogue ep) {
   // 64 KiB of stages (+ 1 KiB: (mean, rstd/16) of the tile's 128 rows, LNC).  ONE array on purpose (see above).
   // (LNC: of the rows of A; RLN: of the rows of the residual - the two never meet in one GEMM)
   __shared__ __attribute__((aligned(16))) __half smem[2 * STAGE + (LNM == LNC || RLN ? 512 : 0)];
@@ -340,8 +340,10 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   if (LNM == LN_NONE && !RLN && gridDim.y > 1) {
     // split-K (GemmArgs::split_k; the weight-gradient GEMMs of the training step: few output tiles, K = the tokens): part
     // blockIdx.y multiplies its K columns (K = the columns of ONE part; slab-major A) into its own partial output
+    // (lda = the row pitch of a row-major A: its parts are column ranges)
     const size_t part = blockIdx.y;
-    a_hi += part * (size_t)K * M; a_lo += part * (size_t)K * M; w += part * (size_t)K * N;
+    const size_t aoff = ep.a_slab ? part * (size_t)K * M : part * (size_t)K;
+    a_hi += aoff; a_lo += aoff; w += part * (size_t)K * N;
     ep.out_f32 += part * (size_t)M * N;
   }
   int tm, tn;
@@ -361,9 +363,9 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #ifdef LTR_GEMM_AROW_MOD   // diag (wrong results): every row tile of a K = 3072 GEMM reads the same few A rows - an L2-resident
                            // stand-in for "the fc1 -> fc2 intermediate never goes to memory" (profiles/r03_fused_and_fp8_probes.txt)
     const int arow = K == 3072 ? min(m0 + row, M - 1) % LTR_GEMM_AROW_MOD : min(m0 + row, M - 1);
-    const size_t aoff = (size_t)arow * (ep.a_slab ? BK16 : K) + c_log * 8;
+    const size_t aoff = (size_t)arow * (ep.a_slab ? BK16 : lda) + c_log * 8;
 #else
-    const size_t aoff = (size_t)min(m0 + row, M - 1) * (ep.a_slab ? BK16 : K) + c_log * 8;
+    const size_t aoff = (size_t)min(m0 + row, M - 1) * (ep.a_slab ? BK16 : lda) + c_log * 8;
 #endif
     ga = a_hi + aoff;
     gl = a_lo + aoff;
@@ -641,7 +643,7 @@ template <int BM_, int BN_, int WM_, int WN_, int SL_, int SSTAGES> struct Small
   static constexpr int EH = ((size_t)BM_ * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2) ? 1 : WM;   // epilogue passes (row blocks of the waves)
   static constexpr int EROWS = BM_ / EH;
   static constexpr size_t LDS_BYTES = (size_t)SSTAGES * STAGE_H * 2 + BM_ * 8;
-  static_assert(SL * (PA + PW) % NW == 0 && PIECES >= 1 && PIECES <= 4, "piece map: 1-4 DMA instructions per wave and stage");
+  static_assert(SL * (PA + PW) % NW == 0 && PIECES >= 1 && PIECES <= 8, "piece map: 1-8 DMA instructions per wave and stage");
   static_assert(SSTAGES >= 3 && SSTAGES <= 8, "counted vmcnt waits cover up to 6 stages in flight");
   static_assert((size_t)EROWS * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2, "epilogue tile must fit the ring");
   static_assert(BM_ % (WM * 16) == 0 && BN_ % (WN * 16) == 0 && (EROWS * BN_ / 8) % (NW * 64) == 0, "tile / wave grid mismatch");
@@ -673,8 +675,17 @@ __device__ __forceinline__ bool xcd_tile(int bid, int tiles_m, int tiles_n, XcdM
 template <int LNM, bool RLN, int BM_, int BN_, int WM_, int WN_, int SL_, int SSTAGES>
 __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::NW * 64)) gemm_f16s_small_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
-    int K, int tiles_m, int tiles_n, XcdMap xmap, Epilogue ep) {
+    int K, int lda, int tiles_m, int tiles_n, XcdMap xmap, Epilogue ep) {
   using C = SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>;
+  if (LNM == LN_NONE && !RLN && gridDim.y > 1) {
+    // split-K (launch_gemm "small-batch split-K"): part blockIdx.y multiplies its K columns (K = the columns of ONE part;
+    // lda = the row pitch of a row-major A) into its own raw f32 partial [M, N]; splitk_epilogue_kernel adds the parts in
+    // part order and runs the epilogue
+    const size_t part = blockIdx.y;
+    const size_t aoff = ep.a_slab ? part * (size_t)K * M : part * (size_t)K;
+    a_hi += aoff; a_lo += aoff; w += part * (size_t)K * N;
+    ep.out_f32 += part * (size_t)M * N;
+  }
   // dynamic LDS on purpose: with a static array hipcc tracks the LDS-DMA stores against every ds_read and drains
   // vmcnt(0) in front of the first fragment read of each stage (ltr_attn.hip has the same note)
   extern __shared__ __attribute__((aligned(16))) __half smem[];
@@ -701,7 +712,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
       const int g = r % (C::PA / 2);
       const int row = min(m0 + g * 16 + row16, M - 1);
       gstep[p] = ep.a_slab ? (size_t)M * BK16 : (size_t)BK16;
-      gsrc[p] = (r < C::PA / 2 ? a_hi : a_lo) + (size_t)row * (ep.a_slab ? BK16 : K) + c_log * 8 + sl * gstep[p];
+      gsrc[p] = (r < C::PA / 2 ? a_hi : a_lo) + (size_t)row * (ep.a_slab ? BK16 : lda) + c_log * 8 + sl * gstep[p];
     } else {
       const int g = r - C::PA;
       const int row = min(n0 + g * 16 + row16, N - 1);
@@ -835,6 +846,55 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
                                tn * P64 + pc);
     }
   }
+}
+
+// Second half of a small-batch split-K GEMM: x = sum over the parts (in part order - deterministic) of the raw f32
+// partials [parts][M][N], then the ordinary epilogue (bias, ReLU, residual / LayerNorm'd residual, f32 / split stores,
+// LayerNorm-fold producer outputs) through the same epilogue_piece the GEMM kernels use: one (row, 8 columns) piece per
+// thread, the 8 lanes of a 64-column piece consecutive.
+template <int LNM, bool RLN>
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __restrict__ partial, int parts, int M, int N,
+                                                              Epilogue ep) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, l8 = gid & 7;
+  const int p64 = N / 64;
+  const int idx = gid >> 3;
+  const int grow = idx / p64, pc = idx % p64;
+  const bool live = grow < M;            // (whole 8-lane groups are live or not: the shuffles inside epilogue_piece stay inside a group)
+  const bool wide = ep.out_hi == nullptr;
+  const int ecol = l8 * (wide ? 4 : 8), ecol_b = wide ? ecol + 32 : ecol + 4;
+  const int ccol = pc * 64 + ecol, ccol_b = pc * 64 + ecol_b;
+  if (!live) return;
+  const size_t o = (size_t)grow * N + ccol;
+  const size_t pstride = (size_t)M * N;
+  float4 va = *reinterpret_cast<const float4*>(partial + o);
+  float4 vb = *reinterpret_cast<const float4*>(partial + o + (ccol_b - ccol));
+  for (int p = 1; p < parts; ++p) {
+    const float4 a = *reinterpret_cast<const float4*>(partial + p * pstride + o);
+    const float4 b = *reinterpret_cast<const float4*>(partial + p * pstride + o + (ccol_b - ccol));
+    va.x += a.x; va.y += a.y; va.z += a.z; va.w += a.w;
+    vb.x += b.x; vb.y += b.y; vb.z += b.z; vb.w += b.w;
+  }
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+  if (ep.resid) {
+    ra = *reinterpret_cast<const float4*>(ep.resid + o);
+    rb = *reinterpret_cast<const float4*>(ep.resid + o + (ccol_b - ccol));
+  }
+  float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;
+  if (ep.bias) {
+    bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
+    bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
+  }
+  float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;
+  if (LNM == LNP) {
+    lnv_a = *reinterpret_cast<const float4*>(ep.ln_gamma + ccol);
+    lnv_b = *reinterpret_cast<const float4*>(ep.ln_gamma + ccol_b);
+    lnv_a.x *= LN_FOLD_SCALE; lnv_a.y *= LN_FOLD_SCALE; lnv_a.z *= LN_FOLD_SCALE; lnv_a.w *= LN_FOLD_SCALE;
+    lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
+  }
+  float2 rst = make_float2(0.f, 0.f);
+  if (RLN) rst = combine_row_stats(ep.r_stats + grow, ep.r_parts, M, 1.f);
+  epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, rst, rst, grow, ccol, ccol_b, o, M, lane, pc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -976,15 +1036,50 @@ int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s, 
 }
 
 namespace {
-int small_m_threshold() { static const int v = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 1024; }(); return v; }
-int mid_m_threshold() { static const int v = [] { const char* e = getenv("LTR_GEMM_MID_M"); return e ? atoi(e) : 3072; }(); return v; }
+// LTR_GEMM_SMALL_M (diag): row count up to which the small-batch kernels are considered at all (0: never - every GEMM on
+// the 128 x 256 two-stage kernel, the round-2 behaviour)
+int small_m_limit() { static const int v = [] { const char* e = getenv("LTR_GEMM_SMALL_M"); return e ? atoi(e) : 4800; }(); return v; }
+
+// Which kernel a GEMM of a small batch runs on, and in how many K parts: measured choice (profiles/r04_small_gemm_lab.txt,
+// diag/small_lab.sh: every tile configuration x split x row count of a scheduler step with 1 ... 256 arrivals, OPT-125m and
+// OPT-350m widths), reduced to thresholds on the row count M.  What the measurements say, in one paragraph: in this regime
+// a CU fills its LDS at ~30 GB/s from lines nobody on its XCD has touched yet and ~3x faster from the XCD's L2, and the
+// chip as a whole at ~6 TB/s - so the best tile is the one that (a) puts about one workgroup on every CU (a second ROUND
+// of workgroups doubles the time: 264 tiles on 256 CUs is the worst case), (b) moves the fewest bytes per workgroup, and
+// above ~1,700 rows the 128 x 256 tile's bytes per FLOP win although it is latency-bound (0.95 us per K-slab).
+//   cfg: -1 = 128 x 256 two-stage kernel; small-batch kernel 0 = 32 x 64, 1 = 64 x 128, 5 = 64 x 256 (2: 128 x 256 behind a
+//   ring of four, 3: 32 x 128, 4: 64 x 64 exist for the lab and lose everywhere)
+struct SmallChoice { int cfg, parts; };
+SmallChoice choose_small(const GemmArgs& g, bool can_split) {
+  const int M = g.M, N = g.N, K = g.K;
+  if (K % 64 || N % 64 || M > small_m_limit()) return {-1, 1};
+  const bool n128 = N % 128 == 0, n256 = N % 256 == 0;
+  auto fits = [&](int c) { return c == 0 || (c == 1 && n128) || (c == 5 && n256); };
+  SmallChoice ch{-1, 1};
+  if (!can_split) {                                  // wide outputs (QKV, fc1) and everything that is not a residual producer
+    if (M <= 400) ch.cfg = ((M + 31) / 32) * (N / 64) <= 512 || !n128 ? 0 : 1;
+    else if (M <= 700) ch.cfg = n128 ? 1 : 0;
+    else if (M <= 1700) ch.cfg = n256 && ((M + 63) / 64) * (N / 256) <= 256 ? 5 : -1;
+  } else if (K <= N + N / 2) {                       // narrow output, short K (out_proj)
+    if (M <= 1100) ch.cfg = 0;
+    else if (M <= 3000) ch.cfg = n128 ? 1 : 0;
+    else ch.cfg = n256 ? 5 : -1;
+  } else {                                           // narrow output, long K (fc2): split-K
+    if (M <= 400) ch = {0, 4};
+    else if (M <= 700) ch = {0, 2};
+    else if (M <= 1100) ch = {n256 ? 5 : 0, n256 ? 4 : 1};
+    else if (M <= 3000) ch = {-1, 4};
+    else ch = {-1, 2};
+  }
+  if (ch.cfg >= 0 && !fits(ch.cfg)) ch.cfg = 0;
+  return ch;
+}
 }  // namespace
 
-// which F16 kernel a GEMM of this shape runs on: -1 the 128 x 256 kernel, 0 the 32 x 64, 1 the 64 x 128 small-batch kernel
+// which F16 kernel a GEMM of this shape runs on: -1 the 128 x 256 kernel, >= 0 a small-batch configuration (profiling classes)
 int gemm_small_config(const GemmArgs& g) {
-  if (g.K % 64 == 0 && g.N % 64 == 0 && g.M <= small_m_threshold()) return 0;
-  if (g.K % 64 == 0 && g.N % 128 == 0 && g.M <= mid_m_threshold()) return 1;
-  return -1;
+  const bool can_split = g.splitk_ws && !g.ln_stats_in && !g.osc_a && g.out_f32 && !g.out_split.hi && !g.relu;
+  return choose_small(g, can_split).cfg;
 }
 
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
@@ -1047,17 +1142,65 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     // stages at one workgroup per CU (SmallCfg<128, 256, 2, 4, 1, 4>, parity-green) - was measured for 1k-23k rows and
     // is slower than both its neighbours everywhere (1,382 tokens: 2.21 vs 1.42 ms per call; 5,928: 3.31 vs 3.02;
     // 23,078: 9.58 vs 8.61): not instantiated.
-    static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 0; }();
-    const int cfg = split > 1 ? -1 : gemm_small_config(g);           // 0: 32 x 64, 1: 64 x 128
+    static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 3; }();
+    static const int force_cfg = [] { const char* e = getenv("LTR_GEMM_FORCE_CFG"); return e ? atoi(e) : -2; }();       // diag: -1 big, 0, 1
+    static const int force_split = [] { const char* e = getenv("LTR_GEMM_FORCE_SPLIT"); return e ? atoi(e) : 0; }();  // diag: parts (1 = off)
+    // tile menu of the small-batch kernel: BM x BN (waves, K stage, ring) - see the instantiation list below
+    static const int CFG_BM[6] = {32, 64, 128, 32, 64, 64}, CFG_BN[6] = {64, 128, 256, 128, 64, 256};
+    // ---- small-batch split-K.  A narrow output (out_proj, fc2: N = H) of a small batch has few tiles (M = 262 rows:
+    // 9 x 12 = 108 on 256 CUs) and, for fc2, a long K: the workgroups that exist each stream hundreds of KB through one
+    // ring at the rate ONE CU pulls from the fabric.  Cutting K into `parts` multiplies the workgroups and divides the
+    // stream each walks; the raw partials (parts x M x N x 4 B: small, because N is) are summed in part order by
+    // splitk_epilogue_kernel.  Only producers of the residual stream qualify (no ReLU, f32 output).
+    const bool can_split = split <= 1 && g.splitk_ws && lnm != LNC && lnm != LNS && g.out_f32 && !g.out_split.hi && !g.relu;
+    SmallChoice ch = split > 1 ? SmallChoice{-1, 1} : choose_small(g, can_split);
+    int cfg = ch.cfg;
+    if (split <= 1 && (force_cfg == -1 || ((force_cfg == 0 || force_cfg == 1 || force_cfg == 5) && g.K % 64 == 0 && g.N % CFG_BN[force_cfg] == 0)))
+      cfg = force_cfg;
+    int parts = can_split ? ch.parts : 1;
+    if (can_split && force_split > 0) parts = force_split;
+    while (parts > 1 && (g.K % (64 * parts) || (size_t)parts * g.M * g.N * 4 > g.splitk_ws_bytes)) parts /= 2;
+    Epilogue epk = ep;                                                 // what the GEMM kernel itself stores
+    int lnm_k = lnm;
+    bool rln_k = rln;
+    if (parts > 1) {
+      epk = Epilogue{};
+      epk.out_f32 = (float*)g.splitk_ws; epk.M = g.M; epk.N = g.N; epk.a_slab = g.a_slab;
+      lnm_k = LN_NONE; rln_k = false;
+    }
+    const int kpart = g.K / parts;
+    auto finish_split = [&]() -> int {                                 // second half of a split launch
+      const unsigned nthreads = (unsigned)g.M * (unsigned)(g.N / 8);
+      const dim3 rgrid((nthreads + 255) / 256);
+      const float* part = (const float*)g.splitk_ws;
+      if (rln) { if (lnm == LNP) splitk_epilogue_kernel<LNP, true><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep);
+                 else splitk_epilogue_kernel<LN_NONE, true><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep); }
+      else if (lnm == LNP) splitk_epilogue_kernel<LNP, false><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep);
+      else splitk_epilogue_kernel<LN_NONE, false><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep);
+      LTR_LAUNCH_CHECK();
+      return LTR_OK;
+    };
     if (cfg >= 0) {
-      const int bm = cfg == 0 ? 32 : 64, bnn = cfg == 0 ? 64 : 128;
+      const int bm = CFG_BM[cfg], bnn = CFG_BN[cfg];
       {
         const int tm_ = (g.M + bm - 1) / bm, tn_ = g.N / bnn;
-        // XCD grid: as many column ranges as keep an XCD's share of the weight matrix near 1.5 MB (and no more than
-        // there are column tiles), the rest of the 8 XCDs split the rows.  map_mode 0: every XCD a row range.
+        // XCD grid (block b runs on XCD b % 8, private 4 MiB L2s): rx row ranges x cx column ranges.  An XCD pulls the
+        // activation rows of its row range and the weight rows of its column range over the fabric, so the launch moves
+        // cx * A + rx * W bytes across it: take the (rx, cx) that minimises that (A = M K 4 bytes, W = N K 2 bytes);
+        // map_mode 0: every XCD a row range (round 3), 1 / 2: column ranges sized from W / as many as possible.
         int cx = 1;
-        if (map_mode) while (cx < 8 && cx * 2 <= tn_ && (size_t)g.N * g.K * 2 / cx > (size_t)3 << 19) cx *= 2;
+        if (map_mode == 1) while (cx < 8 && cx * 2 <= tn_ && (size_t)g.N * g.K * 2 / cx > (size_t)3 << 19) cx *= 2;
         if (map_mode == 2) { cx = 8; while (cx > tn_) cx /= 2; }
+        if (map_mode == 3) {
+          const double A = 4.0 * g.M * g.K, W = 2.0 * g.N * g.K;
+          double best = 1e300;
+          for (int c = 1; c <= 8; c *= 2) {
+            const int r = NXCD / c;
+            if (c > tn_ || r > tm_) continue;
+            const double cost = c * A + r * W;
+            if (cost < best) { best = cost; cx = c; }
+          }
+        }
         XcdMap xm{NXCD / cx, cx, 0};
         {
           int lo, a, b;
@@ -1065,7 +1208,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
           xcd_range(tn_, xm.cx, 0, lo, b);
           xm.per_xcd = a * b;                                          // range 0 is never the shorter one
         }
-        dim3 sgrid(xm.per_xcd * NXCD);
+        dim3 sgrid(xm.per_xcd * NXCD, parts);
 #define LTR_SMALL_LAUNCH(LN, RL, BMv, BNv, WMv, WNv, SLv, STv)                                                             \
   do {                                                                                                                     \
     typedef SmallCfg<BMv, BNv, WMv, WNv, SLv, STv> Cfg;                                                                    \
@@ -1075,30 +1218,40 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     }();                                                                                                                   \
     (void)attr_ok;                                                                                                         \
     gemm_f16s_small_kernel<LN, RL, BMv, BNv, WMv, WNv, SLv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(               \
-        (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, g.K, tm_, tn_, xm, ep);                \
+        (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, kpart, g.K, tm_, tn_, xm, epk);          \
   } while (0)
 #define LTR_SMALL_LN(...)                                                                                                  \
   do {                                                                                                                     \
-    if (rln) { if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, true, __VA_ARGS__); else LTR_SMALL_LAUNCH(LN_NONE, true, __VA_ARGS__); } \
-    else if (lnm == LNP) LTR_SMALL_LAUNCH(LNP, false, __VA_ARGS__);                                                        \
-    else if (lnm == LNC) LTR_SMALL_LAUNCH(LNC, false, __VA_ARGS__);                                                        \
-    else if (lnm == LNS) LTR_SMALL_LAUNCH(LNS, false, __VA_ARGS__);                                                        \
+    if (rln_k) { if (lnm_k == LNP) LTR_SMALL_LAUNCH(LNP, true, __VA_ARGS__); else LTR_SMALL_LAUNCH(LN_NONE, true, __VA_ARGS__); } \
+    else if (lnm_k == LNP) LTR_SMALL_LAUNCH(LNP, false, __VA_ARGS__);                                                      \
+    else if (lnm_k == LNC) LTR_SMALL_LAUNCH(LNC, false, __VA_ARGS__);                                                      \
+    else if (lnm_k == LNS) LTR_SMALL_LAUNCH(LNS, false, __VA_ARGS__);                                                      \
     else LTR_SMALL_LAUNCH(LN_NONE, false, __VA_ARGS__);                                                                    \
   } while (0)
         // (a ring of eight stages for grids of at most one workgroup per CU was measured and is slower: fc2 of a
         // one-request call 21.7 vs 15.7 us, profiles/r03_small_batch.txt)
+        // (lab-only configurations that lost at every row count, profiles/r04_small_gemm_lab.txt: 2 = 128 x 256 behind a
+        // ring of four (SmallCfg<128, 256, 2, 4, 1, 4>), 3 = 32 x 128 (<32, 128, 2, 2, 2, 4>), 4 = 64 x 64 (<64, 64, 2, 2, 2, 4>))
         if (cfg == 0) LTR_SMALL_LN(32, 64, 2, 2, 2, 4);
-        else LTR_SMALL_LN(64, 128, 2, 4, 2, 4);
+        else if (cfg == 1) LTR_SMALL_LN(64, 128, 2, 4, 2, 4);
+        else LTR_SMALL_LN(64, 256, 2, 4, 1, 4);
 #undef LTR_SMALL_LN
 #undef LTR_SMALL_LAUNCH
         LTR_LAUNCH_CHECK();
-        return LTR_OK;
+        return parts > 1 ? finish_split() : LTR_OK;
       }
+    }
+    if (parts > 1) {                     // the 128 x 256 kernel, split: raw partials, then the epilogue kernel
+      grid.y = parts;
+      gemm_f16s_kernel<LN_NONE, false><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N,
+                                                           kpart, g.K, tiles_m, tiles_n, gm, epk);
+      LTR_LAUNCH_CHECK();
+      return finish_split();
     }
     grid.y = split;
 #define LTR_BIG_LAUNCH(LN, RL)                                                                                             \
   gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, \
-                                                g.K / split, tiles_m, tiles_n, gm, ep)
+                                                g.K / split, g.K, tiles_m, tiles_n, gm, ep)
     if (rln) { if (lnm == LNP) LTR_BIG_LAUNCH(LNP, true); else LTR_BIG_LAUNCH(LN_NONE, true); }
     else if (lnm == LNP) LTR_BIG_LAUNCH(LNP, false);
     else if (lnm == LNC) LTR_BIG_LAUNCH(LNC, false);

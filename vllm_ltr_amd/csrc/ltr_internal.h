@@ -84,6 +84,11 @@ struct GemmArgs {
   // Split-K (F16 mode, slab-major A, plain f32 output): K is cut into split_k equal parts (each a multiple of 32), part p
   // writes its partial product to out_f32 + p * M * N; the caller adds the parts up (fixed order).  Always on the 128 x 256 kernel.
   int split_k = 0;
+  // Small-batch split-K (F16 mode, scoring path): scratch for the raw f32 partials [parts][M][N].  When given, launch_gemm
+  // MAY cut K of a narrow-output GEMM of a small batch into parts (more workgroups, shorter operand streams) and finish
+  // with splitk_epilogue_kernel, which adds the parts in part order (deterministic) and runs the epilogue.
+  void* splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
 };
 
 // launchers (each in its own .hip file)

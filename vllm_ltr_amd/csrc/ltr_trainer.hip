@@ -1077,12 +1077,16 @@ int ltr_train_create(const ltr_model_desc* desc, const void* const* weights, int
     set_error("ltr_train_create: listMLE / mse train a 1-label (rank) head (prefill_predictor.py:35-36)"); return LTR_E_INVAL;
   }
   if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) { set_error("ltr_train_create: dropout must be in [0, 1)"); return LTR_E_INVAL; }
+  if (cfg->precision < LTR_TRAIN_PREC_DEFAULT || cfg->precision > LTR_TRAIN_PREC_F32) {
+    set_error("ltr_train_create: precision %d is not one of LTR_TRAIN_PREC_*", cfg->precision); return LTR_E_INVAL;
+  }
   const int want = LTR_WT_GLOBAL_COUNT + d.num_layers * LTR_WL_COUNT;
   if (n_weights != want) { set_error("ltr_train_create: %d weight pointers, expected %d", n_weights, want); return LTR_E_INVAL; }
   ltr_trainer* t = new (std::nothrow) ltr_trainer();
   if (!t) { set_error("ltr_train_create: out of host memory"); return LTR_E_NOMEM; }
   t->d = d; t->cfg = *cfg;
-  { const char* e = getenv("LTR_TRAIN_F32"); t->use_f32 = e && e[0] == '1'; }
+  if (cfg->precision == LTR_TRAIN_PREC_DEFAULT) { const char* e = getenv("LTR_TRAIN_F32"); t->use_f32 = e && e[0] == '1'; }
+  else t->use_f32 = cfg->precision == LTR_TRAIN_PREC_F32;
   t->off.resize(want); t->cnt.resize(want);
   size_t total = 0, wmax = 0;
   for (int i = 0; i < want; ++i) {

@@ -4,24 +4,33 @@ The reference runs the predictor tensor-parallel over the backbone's TP group
 (vllm/engine/llm_engine.py:237): two all-reduces of [T, H] per layer
 (vllm/model_executor/layers/linear.py:577), an embedding all-reduce
 (layers/vocab_parallel_embedding.py:105) and a logits gather
-(layers/logits_processor.py:67).  Requests are independent (causal attention inside a
-prompt only), so here the *batch* is sharded instead: predictor weights are replicated,
-every rank scores a contiguous, token-balanced slice of the unscored requests, and ONE
-collective - an all-gather of f32 scores (RCCL over xGMI; <= 32 KiB per rank at a 64k
-queue) - gives every rank the full score vector; each rank then runs the same
-deterministic rank step.  One process per GPU, ``torch.distributed`` (backend "nccl" =
-RCCL on ROCm; "gloo" in the CPU tests).
+(layers/logits_processor.py:67; vllm/distributed/communication_op.py:13-103).  Requests are
+independent (causal attention inside a prompt only), so here the *batch* is sharded instead:
+predictor weights are replicated, every rank scores a contiguous, token-balanced slice of the
+unscored requests, and ONE collective - an all-gather of f32 scores (RCCL over xGMI; <= 32 KiB per
+rank at a 64k queue) - gives every rank the full score vector; each rank then runs the same
+deterministic rank step.  One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL on ROCm;
+"gloo" in the CPU tests).
 
-All ranks derive the shard map from the same ``cu_seqlens`` and take the
-shard-or-not decision from the same N, so the collective can never be mismatched
-(SURVEY.md section 5 'failure detection').
+All ranks derive the shard map from the same ``cu_seqlens`` and take the shard-or-not decision from
+the same (N, T), so the collective can never be mismatched (SURVEY.md section 5 'failure
+detection'); a peer that never arrives is bounded by ``timeout_s`` (every surviving rank raises).
 """
 from __future__ import annotations
 
+from datetime import timedelta
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+# tokens of one pass of ltr_score on one GPU (ltr_api.hip DEFAULT_CHUNK_TOKENS): north_star shards "only when the
+# queue exceeds a single GPU's batch"
+ONE_PASS_TOKENS = 196608
+
+
+class PeerTimeout(RuntimeError):
+    """A collective of the sharded scoring call did not complete within ``timeout_s``: a peer rank is gone or stuck."""
 
 
 def shard_bounds(cu_seqlens: np.ndarray, world: int) -> List[Tuple[int, int]]:
@@ -41,29 +50,56 @@ def shard_bounds(cu_seqlens: np.ndarray, world: int) -> List[Tuple[int, int]]:
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
-def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """All-gather variable-length f32 score shards: pad to the longest shard, one
-    ``all_gather_into_tensor``, drop the padding.  ``counts[r]`` = shard length of rank r
-    (known to every rank).  ``out`` f32 [sum(counts)]: the compaction writes straight into it (the queue's
-    score slots) instead of a fresh tensor that would have to be copied there."""
+class _GatherBuffers:
+    """Send / receive buffers of the score all-gather, allocated once per (world, largest shard seen) and reused:
+    the collective itself takes ~20 us, three allocations and a zero-fill around it would cost as much again."""
+
+    def __init__(self, device, world: int, staged: bool):
+        self.device, self.world, self.staged = device, world, staged
+        self.cap = 0
+        self.send = self.recv = self.send_h = self.recv_h = None
+
+    def ensure(self, mx: int):
+        if mx <= self.cap:
+            return
+        cap = max(mx, 2 * self.cap, 256)
+        self.send = torch.zeros(cap, dtype=torch.float32, device=self.device)
+        self.recv = torch.empty(self.world * cap, dtype=torch.float32, device=self.device)
+        if self.staged:                  # gloo has no device collectives: pinned host twins
+            pin = torch.cuda.is_available()
+            self.send_h = torch.zeros(cap, dtype=torch.float32, pin_memory=pin)
+            self.recv_h = torch.empty(self.world * cap, dtype=torch.float32, pin_memory=pin)
+        self.cap = cap
+
+
+def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None, out: Optional[torch.Tensor] = None,
+                  bufs: Optional[_GatherBuffers] = None, wait=None) -> torch.Tensor:
+    """All-gather variable-length f32 score shards: padded to the buffer capacity, one
+    ``all_gather_into_tensor``, one compaction.  ``counts[r]`` = shard length of rank r (known to every
+    rank).  ``out`` f32 [sum(counts)]: the compaction writes straight into it (the queue's score slots).
+    ``local`` may already BE ``bufs.send[:n]`` (the scorer wrote there): then nothing is copied before the collective."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     assert len(counts) == world
-    mx = max(max(counts), 1)
-    buf = torch.zeros(mx, dtype=torch.float32, device=local.device)
-    buf[:local.numel()] = local
-    if local.is_cuda and dist.get_backend(group) != "nccl":
+    staged = local.is_cuda and dist.get_backend(group) != "nccl"
+    if bufs is None:
+        bufs = _GatherBuffers(local.device, world, staged)
+    bufs.ensure(max(max(counts), 1))
+    cap = bufs.cap
+    n = local.numel()
+    if n and local.data_ptr() != bufs.send.data_ptr():
+        bufs.send[:n].copy_(local)
+    wait = wait or (lambda work: work.wait())
+    if staged:
         # gloo has no CUDA all-gather: stage through the host.  Only the one-device dry run of the N-rank path
         # (tests, LTR_BENCH_BACKEND=gloo) comes here; production is RCCL ("nccl") on device buffers.
-        out_h = torch.empty(world * mx, dtype=torch.float32)
-        dist.all_gather_into_tensor(out_h, buf.cpu(), group=group)
-        out_g = out_h.to(local.device)
+        bufs.send_h.copy_(bufs.send)
+        wait(dist.all_gather_into_tensor(bufs.recv_h, bufs.send_h, group=group, async_op=True))
+        bufs.recv.copy_(bufs.recv_h, non_blocking=True)
     else:
-        out_g = torch.empty(world * mx, dtype=torch.float32, device=local.device)
-        dist.all_gather_into_tensor(out_g, buf, group=group)
-    g = out_g.view(world, mx)
-    parts = [g[r, :counts[r]] for r in range(world)]
+        wait(dist.all_gather_into_tensor(bufs.recv, bufs.send, group=group, async_op=True))
+    g = bufs.recv.view(world, cap)
+    parts = [g[r, :counts[r]] for r in range(world) if counts[r]]
     if out is not None:
         return torch.cat(parts, out=out)
     return torch.cat(parts)
@@ -74,14 +110,18 @@ class ShardedScorer:
     gets the full score vector back.
 
     scorer: the HIP predictor (:class:`~vllm_ltr_amd.scorer.HipOPTScorer`; anything with
-    ``score_device(ids_dev, cu_dev, cu_host)``), or a plain ``score_fn(ids_shard, cu_shard) -> f32
+    ``score_device(ids_dev, cu_dev, cu_host, out=)``), or a plain ``score_fn(ids_shard, cu_shard) -> f32
     tensor [n_shard]`` over host arrays (the CPU tests put the oracle there).
-    min_requests_to_shard: below it the launch + collective latency outweighs the split
-    (north_star: 'only when the queue exceeds a single GPU's batch'); rank 0 scores alone
-    and broadcasts.
+    min_tokens_to_shard: the batch is sharded when it holds MORE tokens than this - by default the tokens of
+    one pass on one GPU (``ONE_PASS_TOKENS``; north_star: "only when the queue exceeds a single GPU's batch").
+    Below it rank 0 scores alone and broadcasts.
+    min_requests_to_shard: alternative rule on the request count (when given it replaces the token rule).
+    timeout_s: upper bound for every collective of a call; on expiry :class:`PeerTimeout` is raised on every rank that
+    is still alive (None: the process group's own timeout).
     """
 
-    def __init__(self, scorer, device, group=None, min_requests_to_shard: int = 1024):
+    def __init__(self, scorer, device, group=None, min_requests_to_shard: Optional[int] = None,
+                 min_tokens_to_shard: Optional[int] = None, timeout_s: Optional[float] = None):
         import torch.distributed as dist
         self.dist = dist
         self.scorer = scorer if hasattr(scorer, "score_device") else None
@@ -90,47 +130,81 @@ class ShardedScorer:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.min_requests_to_shard = int(min_requests_to_shard)
+        self.backend = dist.get_backend(group)
+        self.min_requests_to_shard = None if min_requests_to_shard is None else int(min_requests_to_shard)
+        self.min_tokens_to_shard = int(ONE_PASS_TOKENS if min_tokens_to_shard is None else min_tokens_to_shard)
+        self.timeout_s = timeout_s
+        self._bufs = _GatherBuffers(self.device, self.world, self.device.type == "cuda" and self.backend != "nccl")
+        self._flag = None
+
+    def shards(self, n: int, tokens: int) -> bool:
+        """The shard-or-not decision; a function of (n, T) only, so every rank takes the same one."""
+        if self.world == 1 or n <= 0:
+            return False
+        if self.min_requests_to_shard is not None:
+            return n >= self.min_requests_to_shard
+        return tokens > self.min_tokens_to_shard
+
+    def _wait(self, work) -> None:
+        if self.timeout_s is None:
+            work.wait()
+            return
+        try:
+            ok = work.wait(timedelta(seconds=self.timeout_s))
+        except RuntimeError as e:                            # gloo / RCCL report the expiry as RuntimeError
+            raise PeerTimeout(f"rank {self.rank}: a collective of the sharded scoring call did not complete within "
+                              f"{self.timeout_s} s - a peer rank is gone or stuck ({e})") from e
+        if ok is False:
+            raise PeerTimeout(f"rank {self.rank}: a collective of the sharded scoring call did not complete within "
+                              f"{self.timeout_s} s")
+
+    def agree_status(self, code: int) -> int:
+        """MAX over the ranks of a small status code (0 = fine): one 4-byte all-reduce, so that all ranks of an SPMD call
+        agree on an error - and on WHICH error - before any of them raises."""
+        if self.world == 1:
+            return int(code)
+        on_dev = self.backend == "nccl"
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=self.device if on_dev else "cpu")
+        self._flag.fill_(int(code))
+        self._wait(self.dist.all_reduce(self._flag, op=self.dist.ReduceOp.MAX, group=self.group, async_op=True))
+        return int(self._flag.item())
 
     def any_rank(self, flag: bool) -> bool:
-        """True on every rank iff ``flag`` is true on at least one (one 4-byte all-reduce): lets all ranks of an SPMD
-        call agree on an error before any of them raises."""
-        if self.world == 1:
-            return bool(flag)
-        on_dev = self.dist.get_backend(self.group) == "nccl"
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return bool(int(t.item()))
+        return self.agree_status(1 if flag else 0) != 0
 
     # ---- the collective part (same on both entry points)
     def _exchange(self, n: int, sharded: bool, bounds, local_fn, whole_fn, out=None) -> torch.Tensor:
         if self.world == 1:
             return whole_fn(out)
-        if not sharded:                                  # same decision on every rank (same n)
+        if not sharded:                                  # same decision on every rank (same n, T)
             if self.rank == 0:
                 s = whole_fn(out).to(self.device, torch.float32)
             else:
                 s = out if out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
             src = self.dist.get_global_rank(self.group, 0) if self.group else 0
-            if s.is_cuda and self.dist.get_backend(self.group) != "nccl":     # one-device dry run (see gather_scores)
+            if s.is_cuda and self.backend != "nccl":     # one-device dry run (see gather_scores)
                 h = s.cpu()
-                self.dist.broadcast(h, src=src, group=self.group)
+                self._wait(self.dist.broadcast(h, src=src, group=self.group, async_op=True))
                 s.copy_(h)
             else:
-                self.dist.broadcast(s, src=src, group=self.group)
+                self._wait(self.dist.broadcast(s, src=src, group=self.group, async_op=True))
             return s
+        counts = [b - a for a, b in bounds]
+        self._bufs.ensure(max(max(counts), 1))
         r0, r1 = bounds[self.rank]
         if r1 > r0:
-            local = local_fn(r0, r1).to(self.device, torch.float32)
+            # the local scores land in the send buffer of the all-gather directly (device scorers take `out=`)
+            local = local_fn(r0, r1, self._bufs.send[:r1 - r0]).to(self.device, torch.float32)
         else:
-            local = torch.zeros(0, dtype=torch.float32, device=self.device)
-        return gather_scores(local, [b - a for a, b in bounds], self.group, out=out)
+            local = self._bufs.send[:0]
+        return gather_scores(local, counts, self.group, out=out, bufs=self._bufs, wait=self._wait)
 
-    def _local_host(self, ids, cu):
+    def _local_host(self, ids, cu, out=None):
         if self.scorer is not None:
             ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
             cu32 = np.ascontiguousarray(cu, dtype=np.int32)
-            return self.scorer.score_device(ids_d, torch.from_numpy(cu32).to(self.device), cu32)
+            return self.scorer.score_device(ids_d, torch.from_numpy(cu32).to(self.device), cu32, out=out)
         return self.score_fn(ids, cu.astype(np.int32))
 
     def score(self, ids: np.ndarray, cu_seqlens: np.ndarray) -> torch.Tensor:
@@ -139,11 +213,11 @@ class ShardedScorer:
         n = cu.shape[0] - 1
         if n <= 0:
             return torch.zeros(0, dtype=torch.float32, device=self.device)
-        sharded = n >= self.min_requests_to_shard
-        bounds = shard_bounds(cu, self.world) if sharded and self.world > 1 else None
+        sharded = self.shards(n, int(cu[-1]))
+        bounds = shard_bounds(cu, self.world) if sharded else None
         ids = np.asarray(ids)
         return self._exchange(n, sharded, bounds,
-                              lambda r0, r1: self._local_host(ids[cu[r0]:cu[r1]], cu[r0:r1 + 1] - cu[r0]),
+                              lambda r0, r1, out: self._local_host(ids[cu[r0]:cu[r1]], cu[r0:r1 + 1] - cu[r0], out),
                               lambda out=None: self._local_host(ids, cu))
 
     def score_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray,
@@ -156,14 +230,14 @@ class ShardedScorer:
         n = cu.shape[0] - 1
         if n <= 0:
             return torch.zeros(0, dtype=torch.float32, device=self.device)
-        sharded = n >= self.min_requests_to_shard
-        bounds = shard_bounds(cu, self.world) if sharded and self.world > 1 else None
+        sharded = self.shards(n, int(cu[-1]))
+        bounds = shard_bounds(cu, self.world) if sharded else None
 
-        def local(r0, r1):
+        def local(r0, r1, out_l):
             t0 = int(cu[r0])
             cu_s = (cu[r0:r1 + 1] - t0).astype(np.int32)
             cu_d = cu_dev[r0:r1 + 1] - t0 if t0 else cu_dev[r0:r1 + 1]
-            return self.scorer.score_device(ids_dev[t0:int(cu[r1])], cu_d.contiguous(), cu_s)
+            return self.scorer.score_device(ids_dev[t0:int(cu[r1])], cu_d.contiguous(), cu_s, out=out_l)
         return self._exchange(n, sharded, bounds, local,
                               lambda out=None: self.scorer.score_device(ids_dev, cu_dev, np.ascontiguousarray(cu_host, np.int32),
                                                                         out=out), out=out)

@@ -36,6 +36,7 @@ prompt (``prompt`` text or ``prompt_token_ids``).
 """
 from __future__ import annotations
 
+import collections
 import itertools
 import operator
 import os
@@ -100,7 +101,8 @@ class _PinnedI32:
 class MI355XRanker:
     def __init__(self, scorer: HipOPTScorer, schedule_type: str = "opt", max_length: int = 2048,
                  tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank",
-                 xpt_distribution=None, group=None, min_requests_to_shard: int = 1024,
+                 xpt_distribution=None, group=None, min_requests_to_shard: Optional[int] = None,
+                 min_tokens_to_shard: Optional[int] = None, collective_timeout_s: Optional[float] = None,
                  mirror_host: bool = False):
         """
         scorer      the HBM-resident predictor
@@ -117,6 +119,10 @@ class MI355XRanker:
                     ranks of the group (every rank must make the same call, SPMD) with one all-gather of the
                     scores (RCCL over xGMI); the reference instead runs the predictor tensor-parallel over the
                     backbone's TP group (llm_engine.py:237).  None: this GPU scores alone.
+        min_tokens_to_shard  shard a scoring call only when it holds more tokens than this (default: one pass of one GPU,
+                    196,608 - north_star: "only when the queue exceeds a single GPU's batch"); ``min_requests_to_shard``
+                    replaces it with a rule on the request count.  ``collective_timeout_s`` bounds every collective of a
+                    sharded call: a dead peer raises :class:`~vllm_ltr_amd.distributed.PeerTimeout` on the surviving ranks.
         mirror_host write ``pri/idle/runs`` back to the request objects every step (what the reference's loops
                     do; costs a D2H copy + a Python loop per step).  Default: device-resident only.
         """
@@ -139,7 +145,8 @@ class MI355XRanker:
         if group is not None:
             from .distributed import ShardedScorer
             self._sharded = ShardedScorer(self.scorer, self.device, group=group,
-                                          min_requests_to_shard=min_requests_to_shard)
+                                          min_requests_to_shard=min_requests_to_shard,
+                                          min_tokens_to_shard=min_tokens_to_shard, timeout_s=collective_timeout_s)
         starv, period = (self.st.starv, self.st.period) if self.st.policy == "opt" else (-1, 0)
         self.queue = DeviceQueue(self.device, starv=starv, period=period, capacity=1 << 13)
         # the slot number lives on the request object under a per-ranker attribute name (two rankers - e.g. in a
@@ -155,7 +162,11 @@ class MI355XRanker:
         self._aged = True                    # False between an order() and the age() that belongs to it
         self._last_reqs: Sequence = ()
         self._last_perm_dev: Optional[torch.Tensor] = None
+        self._order_ran = False
         self.stats = dict(aux_calls=0, requests_scored=0, rank_calls=0, score_seconds=0.0, rank_seconds=0.0)
+        # wall time of the last 1,000 scoring / ordering calls ("calls, requests scored, ms/call")
+        self._score_ms: collections.deque = collections.deque(maxlen=1000)
+        self._rank_ms: collections.deque = collections.deque(maxlen=1000)
 
     # ---- construction from the reference's config objects ------------------------------
     @classmethod
@@ -167,6 +178,8 @@ class MI355XRanker:
         Extra keywords (``xpt_distribution``, ``group``, ...) go to the constructor."""
         if isinstance(cfg, (str, os.PathLike)):
             cfg = PrefillPredictorConfig.from_json(cfg)
+        from .trainer import refuse_activation
+        refuse_activation(cfg.model.activation, "MI355XRanker.from_predictor_config")
         spec, ckpt = load_hf_checkpoint(cfg.model.path)
         if weight_dtype == "auto":       # fp16 checkpoint (trainer.py:215) -> split-fp16 path; fp32 -> exact f32 path
             weight_dtype = checkpoint_weight_dtype(ckpt)
@@ -254,24 +267,54 @@ class MI355XRanker:
         out = scores.tolist()                              # opt.py:408 .tolist()
         for sg, s in zip(seq_groups, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
+        dt = time.perf_counter() - t0
         self.stats["aux_calls"] += 1
         self.stats["requests_scored"] += len(seq_groups)
-        self.stats["score_seconds"] += time.perf_counter() - t0
+        self.stats["score_seconds"] += dt
+        self._score_ms.append(dt * 1e3)
         return out
 
+    def metrics(self) -> dict:
+        """Counters of the ranking path: calls, requests scored, mean ms per call since construction and
+        p50 / p99 over the last 1,000 calls - for ``obtain_aux_scores`` (score) and the ordering step (rank)."""
+        def pct(d):
+            if not d:
+                return dict(n=0, p50_ms=None, p99_ms=None)
+            a = np.sort(np.fromiter(d, np.float64, len(d)))
+            return dict(n=len(a), p50_ms=float(a[len(a) // 2]), p99_ms=float(a[min(len(a) - 1, int(0.99 * len(a)))]))
+        st = self.stats
+        return dict(score=dict(calls=st["aux_calls"], requests=st["requests_scored"],
+                               mean_ms_per_call=st["score_seconds"] * 1e3 / st["aux_calls"] if st["aux_calls"] else None,
+                               last=pct(self._score_ms)),
+                    rank=dict(calls=st["rank_calls"],
+                              mean_ms_per_call=st["rank_seconds"] * 1e3 / st["rank_calls"] if st["rank_calls"] else None,
+                              last=pct(self._rank_ms)),
+                    live_slots=self._live_slots, queue_length=self._n_members,
+                    sharded=self._sharded is not None)
+
     def _check_status(self) -> None:
-        """Raise where the reference's F.embedding raises (a token id outside the vocabulary).  With ``group=`` the
-        flag lives on the rank whose shard held the id: the ranks agree on it first (one tiny all-reduce), so that
-        EVERY rank raises - a rank that carried on alone would enter the next collective without its peers."""
+        """Raise where the reference's F.embedding raises (a token id outside the vocabulary), or when the residual
+        stream left the fp16 range of the LayerNorm-fold operand (LTR_E_RANGE).  With ``group=`` the flag lives on the
+        rank whose shard met the condition: the ranks agree on the status CODE first (one 4-byte MAX all-reduce), so
+        that EVERY rank raises - a rank that carried on alone would enter the next collective without its peers - and
+        every rank names the right condition."""
         err = None
         try:
             self.scorer.check_status()
         except _lib.LtrError as e:
             err = e
-        if self._sharded is not None and self._sharded.any_rank(err is not None) and err is None:
-            err = _lib.LtrError("ltr_score: another rank of the group met a token id outside the predictor's vocabulary "
-                                "(F.embedding raises on it, vocab_parallel_embedding.py:95-106); the scores of this "
-                                "call are invalid on every rank")
+        if self._sharded is not None:
+            mine = 0 if err is None else (2 if err.code == _lib.LTR_E_RANGE else 1)
+            code = self._sharded.agree_status(mine)
+            if code and err is None:
+                if code == 2:
+                    err = _lib.LtrError("ltr_score: on another rank of the group the residual stream left the fp16 range of "
+                                        "the LayerNorm-fold operand; the scores of this call are invalid on every rank - "
+                                        "create the handles with LTR_NO_LN_FOLD=1 for this checkpoint", _lib.LTR_E_RANGE)
+                else:
+                    err = _lib.LtrError("ltr_score: another rank of the group met a token id outside the predictor's "
+                                        "vocabulary (F.embedding raises on it, vocab_parallel_embedding.py:95-106); the "
+                                        "scores of this call are invalid on every rank", _lib.LTR_E_INVAL)
         if err is not None:
             raise err
 
@@ -286,7 +329,7 @@ class MI355XRanker:
         in ONE copy (no synchronisation here)."""
         n = len(reqs)
         self._aged = False           # install(): the wrapped _schedule ages the device slots if nobody calls age()
-        self._last_reqs, self._last_perm_dev = reqs, None
+        self._last_reqs, self._last_perm_dev, self._order_ran = reqs, None, True
         if n == 0:
             self._n_members = 0
             return []
@@ -314,6 +357,7 @@ class MI355XRanker:
         if not want_list:
             self.stats["rank_calls"] += 1
             self.stats["rank_seconds"] += time.perf_counter() - t0
+            self._rank_ms.append((time.perf_counter() - t0) * 1e3)
             return None
         host = self._perm.host[:n]
         host.copy_(perm_dev, non_blocking=True)
@@ -324,6 +368,7 @@ class MI355XRanker:
             self.sync_host(reqs)
         self.stats["rank_calls"] += 1
         self.stats["rank_seconds"] += time.perf_counter() - t0
+        self._rank_ms.append((time.perf_counter() - t0) * 1e3)
         return out
 
     def _xpt_key(self, req) -> float:
@@ -442,9 +487,9 @@ class MI355XRanker:
             # sequence is indexed by CONCATENATION position (waiting+running+swapped, the list order() was given);
             # the ranked list comes back with the decisions in the one copy below
             reqs, perm = self._last_reqs, self._last_perm_dev
-            if perm is None:
-                raise ValueError("plan_step(ordered=None) needs a preceding order(..., want_list=False)")
             n = len(reqs)
+            if perm is None and (n or not self._order_ran):    # (an idle step - order([]) - has no permutation and needs none)
+                raise ValueError("plan_step(ordered=None) needs a preceding order(..., want_list=False)")
         else:
             n = len(ordered)
             perm = torch.arange(n, dtype=torch.int32, device=dev) if n else None   # `ordered` is already in rank order

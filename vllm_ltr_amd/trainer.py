@@ -28,6 +28,17 @@ from .config_predictor import PrefillModelConfig, PrefillPredictorConfig
 from .opt_spec import OPTSpec, save_hf_checkpoint
 
 
+def refuse_activation(activation, who: str) -> None:
+    """``PrefillModelConfig.activation`` names a torch.nn activation the reference applies to the rank logits
+    (prefill_predictor.py:28-29,53,80).  This path computes the raw ``score.weight`` logit (what opt.py:389-397 serves and
+    every config under train/configs/ asks for: null); a config that names one would silently get a different function."""
+    if activation not in (None, "Identity"):
+        raise NotImplementedError(f"{who}: PrefillModelConfig.activation = {activation!r} is not supported - this path "
+                                  "scores / trains the raw logit (activation null, as in every shipped config: "
+                                  "train/configs/*.txt, trainer.py:203-216); prefill_predictor.py:28-29,80 would apply "
+                                  f"torch.nn.{activation} to it")
+
+
 def len2label(length: int, label_max_length: int = 8192, label_group_size: int = 1) -> int:
     """``RankingDataset.__len2label__`` (trainer.py:52-54): shorter generations get LARGER labels."""
     return label_max_length // label_group_size - min(label_max_length, length) // label_group_size
@@ -36,15 +47,21 @@ def len2label(length: int, label_max_length: int = 8192, label_group_size: int =
 class HipPredictorTrainer:
     def __init__(self, spec: OPTSpec, ckpt: Dict[str, np.ndarray], device: str = "cuda:0", lr: float = 2e-5,
                  weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, loss: str = "listMLE",
-                 dropout: float = 0.0, seed: int = 42, precision: str = "split"):
+                 dropout: float = 0.0, seed: int = 42, precision: Optional[str] = None, activation: Optional[str] = None):
         """Defaults are the reference's: ``--lr 2e-5 --wc 0.01`` (trainer.py:28-29), Adam's betas / eps, seed 42 (:86).
         ``dropout``: HF OPT trains with 0.1; 0 keeps the step reproducible against other implementations.
-        ``precision``: how the dense layers multiply - "split" (default): both operands as two fp16 terms on the fp16
+        ``precision``: how the dense layers multiply - "split": both operands as two fp16 terms on the fp16
         matrix cores (f32-grade products, f32 accumulation; the reference itself trains under fp16 autocast,
-        trainer.py:147) and the scoring path's MFMA attention in the forward; "f32": the exact-f32 MFMA everywhere."""
-        if precision not in ("split", "f32"):
-            raise ValueError(f"precision {precision!r}: 'split' or 'f32'")
-        self.precision = precision
+        trainer.py:147) and the scoring path's MFMA attention in the forward; "f32": the exact-f32 MFMA everywhere;
+        None (default): "split" unless the process environment holds LTR_TRAIN_F32=1.  The choice
+        travels in ``ltr_train_config.precision`` - per handle, no process-wide state.
+        ``activation``: ``PrefillModelConfig.activation`` (prefill_predictor.py:28-29,80 applies it to the rank logits
+        in the training forward).  Every shipped config says null; anything else is refused by name rather than trained
+        as a different function."""
+        if precision not in _lib.TRAIN_PRECISIONS:
+            raise ValueError(f"precision {precision!r}: 'split', 'f32' or None")
+        refuse_activation(activation, "HipPredictorTrainer")
+        self.precision = precision or ("f32" if os.environ.get("LTR_TRAIN_F32", "")[:1] == "1" else "split")
         if not torch.cuda.is_available():
             raise _lib.LtrError("HipPredictorTrainer needs a ROCm GPU (no CPU fallback on the product path)")
         if loss == "neuralNDCG":
@@ -80,19 +97,12 @@ class HipPredictorTrainer:
                               spec.num_attention_heads, spec.word_embed_proj_dim,
                               spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
                               1 if spec.do_layer_norm_before else 0, _lib.LTR_W_F32)
-        cfg = _lib.TrainConfig(lr, betas[0], betas[1], eps, weight_decay, _lib.LOSSES[loss], 1e-10, -1.0, dropout, seed)
+        cfg = _lib.TrainConfig(lr, betas[0], betas[1], eps, weight_decay, _lib.LOSSES[loss], 1e-10, -1.0, dropout,
+                               _lib.TRAIN_PRECISIONS[precision], seed)
         self._h = C.c_void_p()
-        prev = os.environ.get("LTR_TRAIN_F32")
-        os.environ["LTR_TRAIN_F32"] = "1" if precision == "f32" else "0"        # read by ltr_train_create
-        try:
-            with torch.cuda.device(self.device):
-                _lib.check(self.lib.ltr_train_create(C.byref(desc), ptrs, len(g), C.byref(cfg), self._stream(), C.byref(self._h)),
-                           "ltr_train_create")
-        finally:
-            if prev is None:
-                del os.environ["LTR_TRAIN_F32"]
-            else:
-                os.environ["LTR_TRAIN_F32"] = prev
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ltr_train_create(C.byref(desc), ptrs, len(g), C.byref(cfg), self._stream(), C.byref(self._h)),
+                       "ltr_train_create")
         del g                                    # the library copied the weights
         self._n_weights = len(ptrs)
         self._ws: Optional[torch.Tensor] = None
@@ -172,12 +182,19 @@ class HipPredictorTrainer:
         return logits.cpu().numpy()
 
     def fit(self, train: Sequence, test: Sequence, epochs: int = 1, batch_size: int = 32, seed: int = 42,
-            log=print) -> List[dict]:
+            log=print, label_max_length: int = 8192, label_group_size: int = 1) -> List[dict]:
         """The loop of train/trainer.py:134-200.  ``train`` / ``test``: sequences of ``(token_ids, label)`` with
         ``label = len2label(output_length, ...)`` (RankingDataset, :50-66).  Per epoch: the examples in a fresh random
         order (``DataLoader(shuffle=True)``, :118) in slates of ``batch_size`` -> :meth:`step`; then the evaluation pass
         (:167-200): predictions of the test examples, Kendall's tau against their labels (``scipy.stats.kendalltau``,
-        :195) and, for crossentropy, the accuracy (:198-199).  Returns one record per epoch."""
+        :195) and, for crossentropy, the accuracy (:198-199).  Returns one record per epoch.
+
+        The reference evaluates against TWO labels of a test example: tau against ``RankingTestDataset``'s UNGROUPED
+        label ``label_max_length - min(label_max_length, len)`` (:68-86, group size 1 whatever ``--label-group-size``
+        says) and the accuracy against the TRAIN data set's grouped ``len2label(origin_len)`` (:191,198-199).  A test item
+        ``(token_ids, label, origin_len)`` gets exactly that (``label`` = the ungrouped test label; the grouped one is
+        rebuilt from ``origin_len`` with ``label_max_length`` / ``label_group_size``); a 2-tuple ``(token_ids, label)``
+        uses the one label for both, which equals the reference only for ``label_group_size == 1``."""
         from scipy.stats import kendalltau
         from .scorer import HipOPTScorer
         rs = np.random.RandomState(seed)
@@ -191,17 +208,19 @@ class HipPredictorTrainer:
                 total += self.step(ids, cu, np.asarray([train[i][1] for i in idx], np.float32),
                                    shuffle=rs.permutation(len(idx)) if self.loss == "listMLE" else None)
                 nb += 1
-            preds, truth = [], []
+            preds, truth, train_labels = [], [], []
             for b0 in range(0, len(test), batch_size):
                 chunk = test[b0:b0 + batch_size]
                 ids, cu = HipOPTScorer.pack([t[0] for t in chunk])
                 out = self.predict(ids, cu)
                 preds.extend(out.argmax(-1).tolist() if self.loss == "crossentropy" else out[:, 0].tolist())   # :186-189
-                truth.extend(t[1] for t in chunk)
+                truth.extend(t[1] for t in chunk)                                                               # :190
+                train_labels.extend(len2label(t[2], label_max_length, label_group_size) if len(t) > 2 else t[1]
+                                    for t in chunk)                                                             # :191
             tau, pval = kendalltau(truth, preds) if len(truth) > 1 else (float("nan"), float("nan"))
             rec = dict(epoch=epoch + 1, loss=total / max(nb, 1), kendall_tau=float(tau), p_value=float(pval))
             if self.loss == "crossentropy":
-                rec["acc"] = float((np.asarray(truth) == np.asarray(preds)).mean())
+                rec["acc"] = float((np.asarray(train_labels) == np.asarray(preds)).mean())                   # :198-199
             if log:
                 log(f"Epoch {epoch + 1}, Loss: {rec['loss']}")                               # :165
                 log(f"Kendall's Tau: {rec['kendall_tau']}, p-value: {rec['p_value']}")        # :196
