@@ -783,9 +783,9 @@ def test_wider_opt_shapes_two_layers(dev, name, hidden, ffn, heads, pre_ln, embe
     err = np.abs(got - want).max()
     print(f"OPT {name} shape, 2 layers: max|score - oracle| = {err:.3e}")
     assert np.isfinite(got).all() and err <= TOL
-    for i in (0, 5, 11, 15):                                          # alone (small-tile kernels) = inside the batch, bit for bit
-        one = sc.score(ids[cu[i]:cu[i + 1]], np.array([0, lens[i]], np.int32))
-        assert one[0] == got[i], (i, one[0], got[i])
+    for i in (0, 5, 11, 15):                  # alone (small-batch kernels, split-K) against inside the batch: f32 rounding
+        one = sc.score(ids[cu[i]:cu[i + 1]], np.array([0, lens[i]], np.int32))            # (K = 8,192 sums: a few 1e-6)
+        assert abs(one[0] - got[i]) <= 1e-5 and abs(one[0] - want[i]) <= TOL, (i, one[0], got[i])
     os.environ["LTR_NO_LN_FOLD"] = "1"
     try:
         plain = _scorer(spec, ckpt, dev, "f16")

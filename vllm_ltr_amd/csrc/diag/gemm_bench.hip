@@ -5,6 +5,7 @@
 //   LD_LIBRARY_PATH=. /tmp/gemm_bench [M=196608] [H=768] [F=3072] [reps=20]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <hip/hip_fp16.h>
 #include "ltr_internal.h"
@@ -76,6 +77,17 @@ int main(int argc, char** argv) {
   struct Item { const char* name; GemmArgs* g; double flop; } items[4] = {
       {"qkv", &g_qkv, 2.0 * M * 3 * H * H}, {"out_proj", &g_out, 2.0 * M * H * H}, {"fc1", &g_fc1, 2.0 * M * F * H}, {"fc2", &g_fc2, 2.0 * M * H * F}};
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  if (const char* only = getenv("BENCH_ONLY")) {   // PMC passes: one shape only, `reps` launches (counters are summed per kernel name)
+    for (auto& it : items)
+      if (!strcmp(only, it.name)) {
+        for (int r = 0; r < reps; ++r) launch_gemm(LTR_W_F16, *it.g, 0);
+        (void)hipDeviceSynchronize();
+        printf("%s x %d at M=%d\n", it.name, reps, M);
+        return 0;
+      }
+    printf("BENCH_ONLY=%s: no such shape\n", only);
+    return 1;
+  }
   // the layer sequence, as in the model (keeps the chip in the model's power state), then each shape alone
   for (int w = 0; w < 3; ++w) for (auto& it : items) if (launch_gemm(LTR_W_F16, *it.g, 0)) { printf("launch failed: %s\n", it.name); return 1; }
   (void)hipDeviceSynchronize();

@@ -110,7 +110,8 @@ struct Workspace {
   AOp a;           // operand [Tc, H]  LN out / attention out / (De!=H: token rows)
   AOp qkv;         // [Tc, 3H]: f32 (F32 mode) or fp16 hi|lo planes written by the QKV GEMM epilogue
   AOp f;           // operand [Tc, F]  ReLU(fc1)
-  int32_t* blk;    // attention work list: int32 [Nc + 4] prefix + int4 [Tc / 64 + Nc + 1] block descriptors
+  int32_t* blk;    // attention work list: int32 [Nc + 4] prefix + int4 [Tc / 32 + Nc + 1] block descriptors
+  size_t blk_bytes;
   // LayerNorm fold: second operand buffer (out_proj reads `a` while it writes the fc1 operand) and the row-piece
   // statistics written by fc2 (for the next layer's LN1) / out_proj (for LN2): float2 [H / 64][Tc] each
   AOp a2;
@@ -139,7 +140,8 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, boo
   char* a = (char*)take(Tc * H * esz);
   char* qkv = (char*)take(Tc * 3 * H * esz);
   char* f = (char*)take(Tc * F * esz);
-  ws.blk = (int32_t*)take((Nc + 4) * 4 + (Tc / 64 + Nc + 1) * 16);
+  ws.blk_bytes = (Nc + 4) * 4 + (Tc / 32 + Nc + 1) * 16;       // (32-query blocks: the split-K/V attention of small passes)
+  ws.blk = (int32_t*)take(ws.blk_bytes);
   if (ln_fold) {
     char* a2 = (char*)take(Tc * H * esz);
     ws.a2 = AOp{a2, a2 ? a2 + Tc * H * 2 : nullptr};
@@ -305,7 +307,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       {
         ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
         rc = launch_attention(m->dbg_attn_valu && wd == LTR_W_F16 ? -1 : wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads,
-                              ws.blk, ws.a, L == 0, s);
+                              ws.blk, ws.a, L == 0, s, nullptr, ws.blk_bytes);
       }
       if (rc) return rc;
     }
@@ -788,7 +790,7 @@ int ltr_attention(ltr_handle h, const void* qkv, const int32_t* cu_seqlens, int3
   AOp in{(void*)qkv, f16 ? (void*)((char*)qkv + (size_t)T * 3 * H * 2) : nullptr};
   AOp o{out, f16 ? (void*)((char*)out + (size_t)T * H * 2) : nullptr};
   return launch_attention(d.weight_dtype, in, cu_seqlens, N, T, (int)H, d.num_heads, (int32_t*)workspace, o, 1,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, nullptr, ws_bytes);
 }
 
 int ltr_rank_step(const float* scores, int32_t* pri, int32_t* idle, int32_t* runs, const uint32_t* tiebreak,

@@ -222,8 +222,19 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
+#ifdef LTR_ATTN_TIMELINE
+__device__ unsigned long long g_attn_tl[4096 * 5];
+#endif
+// SKV ("split K/V", the small grids of a scheduler step with a few arrivals): a workgroup owns 32 queries instead of 128 and
+// its four waves share them.  Per K/V tile a wave spends ~2,300 cycles (12 + 12 MFMAs of 32 x 32 x 16, the softmax, the
+// fragment reads - diag/attn_small_timeline.hip), and a lone workgroup has nothing to hide that behind: the last query
+// block of a 262-token prompt walks nine tiles = 9 us.  Here wave w walks the tiles w, w + 4, ... as its OWN stream - it
+// loads them itself into a private two-stage ring (no workgroup barrier in the loop) - and the four (m, l, O) states are
+// merged through LDS at the end: nine tiles become three per wave.  128 KiB of LDS, one workgroup per CU.
+// (Dealing the tiles to the waves while everybody still loads every tile behind a barrier gains nothing: the barrier makes
+// each iteration as long as its one working wave.)
+template <int NW, bool SKV>
+__global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
     const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
     __half* __restrict__ out_hi, __half* __restrict__ out_lo,
@@ -231,9 +242,13 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   // 48 KiB ring, tiles it+1 and it+2 in flight.  Dynamic LDS on purpose: with a static array hipcc tracks the
   // LDS-DMA stores against every ds_read and drains vmcnt(0) in front of the first fragment read
   extern __shared__ __attribute__((aligned(16))) __half smem[];
-  constexpr int QBLK = 32 * NW;
+  constexpr int QBLK = SKV ? 32 : 32 * NW;
   static_assert(NW == 4, "load map below assumes 4 waves (one 8-row group of each plane per wave)");
 
+#ifdef LTR_ATTN_TIMELINE
+  const unsigned long long tl0 = __builtin_readcyclecounter();
+  unsigned long long tl1 = 0, tl2 = 0;
+#endif
   const int b = blockIdx.x;
   if (b >= blk_start[n_req]) return;
   const int head = blockIdx.y;
@@ -243,8 +258,11 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   const int qblk0 = desc.y;
   const int t0 = desc.z;
   const int L = desc.w;
-  const int q0 = qblk0 + wave * 32;
+  const int q0 = SKV ? qblk0 : qblk0 + wave * 32;
   const bool wave_active = q0 < L;
+#ifdef LTR_ATTN_TIMELINE
+  if (L > 0) tl1 = __builtin_readcyclecounter();       // the descriptor has arrived
+#endif
   const size_t ld = (size_t)3 * H;
   const int lq = lane & 31, lh = lane >> 5;
 
@@ -281,22 +299,55 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
   // Ring of three stages: when tile `it` is multiplied, tiles it+1 and it+2 are in flight
   // (prompts are short, so a wave's per-tile math is shorter than the HBM round trip; one
   // tile of look-ahead left the waves parked on vmcnt).  Counted waits: 4 loads per tile.
-  issue(0, 0);
-  if (ntile > 1) issue(1, TK);
+  // SKV: this wave's private stream - tile j of the wave = tile (wave + NW j) of the block, its own two-stage ring
+  auto issue_own = [&](int stage, int kt) {
+    __half* base = smem + (wave * 2 + stage) * ATT_STAGE;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ ((row >> 1) & 7), vcc = (lane & 7) ^ (((row >> 1) & 1) * LTR_ATTN_VSWZ);
+      const size_t rowoff = (size_t)(t0 + min(kt + row, L - 1)) * ld + head * D;
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc * 8), (lds_void*)(base + r * 8 * D), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc * 8), (lds_void*)(base + PLANE_H + r * 8 * D), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + vcc * 8), (lds_void*)(base + 2 * PLANE_H + r * 8 * D), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vcc * 8), (lds_void*)(base + 3 * PLANE_H + r * 8 * D), 16, 0, 0);
+    }
+  };
+  const int nown = SKV ? (ntile > wave ? (ntile - wave + NW - 1) / NW : 0) : 0;      // tiles of this wave's stream
+  if (SKV) {
+    if (nown > 0) issue_own(0, wave * TK);
+    if (nown > 1) issue_own(1, (wave + NW) * TK);
+  } else {
+    issue(0, 0);
+    if (ntile > 1) issue(1, TK);
+  }
   // Pin the Q fragments here: hipcc then waits for the (older) Q loads with a counted vmcnt BEFORE the
   // loop; left to itself it re-waits vmcnt(0) at their first use in every iteration, which also drains
   // the look-ahead tiles.
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qh[ks]), "v"(ql[ks]));
-  for (int it = 0; it < ntile; ++it) {
-    const int kt = it * TK;
-    if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it landed, it+1 may fly
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // raw barrier: __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for the look-ahead tiles too
-    __builtin_amdgcn_s_barrier();                       // everyone's rows landed; tile it-1 fully consumed
-    if (it + 2 < ntile) issue((it + 2) % NSTAGE, kt + 2 * TK);
-    if (!wave_active || kt > q0) continue;              // wave-uniform: past this wave's diagonal
-    const __half* s_khi = smem + (it % NSTAGE) * ATT_STAGE;
+  for (int it = 0; it < (SKV ? nown : ntile); ++it) {
+    const int kt = SKV ? (wave + NW * it) * TK : it * TK;
+    const __half* s_khi;
+    if (SKV) {
+      // my tile `it` has landed once only my NEXT tile's 16 loads are outstanding; no workgroup barrier: nobody else
+      // touches my ring
+      if (it + 1 < nown) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      s_khi = smem + (wave * 2 + (it & 1)) * ATT_STAGE;
+    } else {
+      if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it landed, it+1 may fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // raw barrier: __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for the look-ahead tiles too
+      __builtin_amdgcn_s_barrier();                       // everyone's rows landed; tile it-1 fully consumed
+#ifdef LTR_ATTN_TIMELINE
+      if (it == 0) tl2 = __builtin_readcyclecounter();
+#endif
+      if (it + 2 < ntile) issue((it + 2) % NSTAGE, kt + 2 * TK);
+      if (!wave_active || kt > q0) continue;              // wave-uniform: past this wave's diagonal
+      s_khi = smem + (it % NSTAGE) * ATT_STAGE;
+    }
     const __half* s_klo = s_khi + PLANE_H;
     const __half* s_vhi = s_khi + 2 * PLANE_H;
     const __half* s_vlo = s_khi + 3 * PLANE_H;
@@ -375,13 +426,51 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
       }
     }
+  
+    if (SKV) {
+      // the stage just consumed is refilled with my tile it + 2 (the reads of this iteration are complete: the P V MFMAs
+      // above depend on them)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (it + 2 < nown) issue_own(it & 1, (wave + NW * (it + 2)) * TK);
+    }
   }
   // ---- output.  Lane (lq, lh) holds 4 consecutive d of query lq per (dt, j): stored directly that
   // is 32 rows x 16 B per instruction (every 128-B line written in eight pieces).  Transpose through
   // the (now idle) ring instead: per wave a [32 queries][64 d] tile per fp16 plane, row pitch 136 B
   // (conflict-free 8-byte accesses), read back so that 16 lanes cover one 128-B row.
   __syncthreads();                                      // every wave is done with the last K/V tile
+#ifdef LTR_ATTN_TIMELINE
+  const unsigned long long tl3 = __builtin_readcyclecounter();
+#endif
   if (!wave_active) return;
+  if (SKV) {
+    // merge the waves' online-softmax states into wave 0 (behind its output staging area): per lane 32 accumulators + (m, l)
+    constexpr int MERGE0 = 2 * 32 * 136;                // bytes: wave 0's [32 queries][64 d] hi | lo staging tile
+    constexpr int MSTRIDE = 34 * 64 * 4;                // bytes per wave: 34 floats per lane
+    float* mg = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + MERGE0 + (wave - 1) * MSTRIDE);
+    if (wave != 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { mg[i * 64 + lane] = o[0][i]; mg[(16 + i) * 64 + lane] = o[1][i]; }
+      mg[32 * 64 + lane] = m; mg[33 * 64 + lane] = l;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + MERGE0 + (w - 1) * MSTRIDE);
+      const float mw = src[32 * 64 + lane], lw = src[33 * 64 + lane];
+      const float m_new = fmaxf(m, mw);
+      const float a = __builtin_amdgcn_exp2f(m - m_new), b = __builtin_amdgcn_exp2f(mw - m_new);   // (a wave without tiles: m = NEG, b = 0)
+      m = m_new;
+      l = l * a + lw * b;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] = o[0][i] * a + src[i * 64 + lane] * b;
+        o[1][i] = o[1][i] * a + src[(16 + i) * 64 + lane] * b;
+      }
+    }
+  }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
   // training: the backward recomputes the softmax from the log-sum-exp of the row (log2 domain, like the f32 kernel;
@@ -415,6 +504,14 @@ __global__ void __launch_bounds__(NW * 64, 3) attn_f16s_kernel(
       *reinterpret_cast<uint2*>(out_lo + ob) = vl;
     }
   }
+#ifdef LTR_ATTN_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int slot = blockIdx.y * gridDim.x + blockIdx.x;
+  if (tid == 0 && slot < 4096) {
+    g_attn_tl[slot * 5 + 0] = tl0; g_attn_tl[slot * 5 + 1] = tl1; g_attn_tl[slot * 5 + 2] = tl2; g_attn_tl[slot * 5 + 3] = tl3;
+    g_attn_tl[slot * 5 + 4] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 
@@ -846,6 +943,10 @@ __global__ void __launch_bounds__(256) attn_bwd_planes_kernel(const float* __res
 }  // namespace
 
 // the work list of `qb`-query blocks alone (the training backward walks 64-query blocks whatever kernel ran the forward)
+#ifdef LTR_ATTN_TIMELINE
+int attn_timeline_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_tl), sizeof(unsigned long long) * 4096 * 5); }
+#endif
+
 int launch_attention_blocks(const int32_t* cu, int n_req, int qb, int32_t* blk_start, hipStream_t s) {
   if (n_req == 0) return LTR_OK;
   int4* blk_desc = reinterpret_cast<int4*>(blk_start + ((n_req + 1 + 3) & ~3));
@@ -855,7 +956,7 @@ int launch_attention_blocks(const int32_t* cu, int n_req, int qb, int32_t* blk_s
 }
 
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
-                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2) {
+                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2, size_t blk_bytes) {
   if (n_req == 0 || T == 0) return LTR_OK;
   if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
   const float scale_log2e = 0.125f * 1.4426950408889634f;   // d^-0.5 (opt.py:73) * log2(e)
@@ -863,13 +964,32 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
   int4* blk_desc = reinterpret_cast<int4*>(blk_start + ((n_req + 1 + 3) & ~3));
   if (wdtype == LTR_W_F16) {
     constexpr int NW = 4;
+    // small passes (a scheduler step with a few arrivals): 32-query workgroups whose waves split the K/V tiles - when the
+    // scratch holds the longer work list (T / 32 + n_req descriptors)
+    // (read per call - a getenv costs nothing next to a launch - so that a test can move it; 0: never.  Measured: one-request
+    // call 641 vs 676 us, no gain from ~900 tokens per pass)
+    const char* skv_env = getenv("LTR_ATTN_SPLITKV_TOKENS");
+    const int skv_tokens = skv_env ? atoi(skv_env) : 600;
+    const bool skv = lse2 == nullptr && T <= skv_tokens &&
+                     blk_bytes >= (size_t)((n_req + 1 + 3) & ~3) * 4 + ((size_t)T / 32 + n_req + 1) * 16;
+    const int qb = skv ? 32 : 32 * NW;
     if (build_blocks) {   // the work list depends on cu_seqlens only: built once per pass, reused by every layer
-      attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, 32 * NW, blk_start, blk_desc);
+      attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, qb, blk_start, blk_desc);
       LTR_LAUNCH_CHECK();
     }
-    dim3 grid(T / (32 * NW) + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
-    attn_f16s_kernel<NW><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
-                                                  n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+    dim3 grid(T / qb + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
+    if (skv) {
+      constexpr int LDS = NW * 2 * ATT_STAGE * sizeof(__half);      // a private two-stage ring per wave: 128 KiB
+      static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)attn_f16s_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+      }();
+      (void)attr_ok;
+      attn_f16s_kernel<NW, true><<<grid, NW * 64, LDS, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
+                                                            n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+    } else {
+      attn_f16s_kernel<NW, false><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>(
+          (const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc, n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+    }
   } else {
     if (build_blocks) {
       attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, QB, blk_start, blk_desc);

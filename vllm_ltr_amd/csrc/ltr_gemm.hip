@@ -690,6 +690,10 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
   // vmcnt(0) in front of the first fragment read of each stage (ltr_attn.hip has the same note)
   extern __shared__ __attribute__((aligned(16))) __half smem[];
   float2* s_stat = reinterpret_cast<float2*>(smem + SSTAGES * C::STAGE_H);
+#ifdef LTR_GEMM_TIMELINE
+  const unsigned long long tl0 = __builtin_readcyclecounter();
+  unsigned long long tl1 = 0;
+#endif
   int tm, tn;
   if (!xcd_tile(blockIdx.x, tiles_m, tiles_n, xmap, tm, tn)) return;
   const int m0 = tm * BM_, n0 = tn * BN_;
@@ -755,6 +759,9 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NP) : "memory"); break;
     }
     __builtin_amdgcn_s_barrier();                       // everyone's pieces of stage kt landed; stage kt-1 fully consumed
+#ifdef LTR_GEMM_TIMELINE
+    if (kt == 0) tl1 = __builtin_readcyclecounter();
+#endif
     if (kt + SSTAGES - 1 < nst) issue((kt + SSTAGES - 1) % SSTAGES, kt + SSTAGES - 1);
     const __half* sb = smem + (kt % SSTAGES) * C::STAGE_H;
 #pragma unroll
@@ -783,6 +790,9 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
         }
     }
   }
+#ifdef LTR_GEMM_TIMELINE
+  const unsigned long long tl2 = __builtin_readcyclecounter();
+#endif
   // ---- epilogue through LDS (the ring is idle): the tile - or, when it does not fit, one wave-row block of it after
   // the other - then one (row, 8 columns) piece per lane and pass.  (Fetching the bias / LayerNorm-fold vectors /
   // residual row of the piece BEFORE the K loop, to take them off the tail of the launch, was measured and is not
@@ -846,6 +856,13 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
                                tn * P64 + pc);
     }
   }
+#ifdef LTR_GEMM_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores have left the wave)
+  if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) {
+    g_timeline[blockIdx.x * 4 + 0] = tl0; g_timeline[blockIdx.x * 4 + 1] = tl1;
+    g_timeline[blockIdx.x * 4 + 2] = tl2; g_timeline[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // Second half of a small-batch split-K GEMM: x = sum over the parts (in part order - deterministic) of the raw f32

@@ -120,7 +120,9 @@ int launch_embed_gather(int wdtype, const int64_t* ids, const int32_t* cu, int N
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]*/, int n_req,
                      int T, int H, int n_heads, int32_t* blk_start /*scratch: (n_req+4)*4 + (T/64+n_req+1)*16 bytes*/, AOp out,
                      int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s,
-                     float* lse2 = nullptr /*[T, heads] log2-domain log-sum-exp of every query row (training), nullable*/);
+                     float* lse2 = nullptr /*[T, heads] log2-domain log-sum-exp of every query row (training), nullable*/,
+                     size_t blk_bytes = 0 /*bytes behind blk_start when more than the minimum: (n_req+4)*4 + (T/32+n_req+1)*16
+                                            lets small passes run the split-K/V variant (32-query blocks)*/);
 
 int launch_attention_bwd_planes(const float* x, size_t n /*multiple of 8*/, void* planes /*[2][n] halves*/, hipStream_t s);
 // training: dqkv [T, 3H] of the attention block on the split-fp16 MFMA (ltr_attn.hip "attention BACKWARD")

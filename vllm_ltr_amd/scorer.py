@@ -205,10 +205,13 @@ class HipOPTScorer:
                                              tok_out.data_ptr() if tok_out is not None else None,
                                              self._stream()), "ltr_embed_gather")
 
-    def attention_device(self, qkv: torch.Tensor, cu_dev: torch.Tensor, N: int, T: int, out: torch.Tensor) -> None:
+    def attention_device(self, qkv: torch.Tensor, cu_dev: torch.Tensor, N: int, T: int, out: torch.Tensor,
+                         split_kv: bool = True) -> None:
         """The varlen causal attention kernel alone (``ltr_attention``).  f16 mode: ``qkv`` fp16 [2, T, 3H] (hi | lo planes),
-        ``out`` fp16 [2, T, H]; f32 mode: f32 [T, 3H] -> f32 [T, H]."""
-        need = (N + 4) * 4 + (T // 64 + N + 1) * 16
+        ``out`` fp16 [2, T, H]; f32 mode: f32 [T, 3H] -> f32 [T, H].  ``split_kv``: hand over the larger work-list scratch
+        (32-query blocks) with which passes of <= 600 tokens run the split-K/V variant, as they do inside ``ltr_score``;
+        False: the minimal scratch of include/ltr_hip.h - always the 128-query kernel."""
+        need = (N + 4) * 4 + (T // (32 if split_kv else 64) + N + 1) * 16
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.ltr_attention(self._h, qkv.data_ptr(), cu_dev.data_ptr(), N, T, out.data_ptr(), ws.data_ptr(),
                                           ws.numel(), self._stream()), "ltr_attention")
