@@ -85,6 +85,47 @@ def test_class_mode_head_at_8192_labels_true_width(dev):
     assert got2[0] == min(win, lo, hi)
 
 
+def test_class_head_logits_in_row_blocks():
+    """The GEMM head keeps the padded class logits for a BLOCK of rows at a time (row windows of the label GEMM + argmax
+    per block; 64 MB at most), so the scoring workspace does not grow with requests x labels.  In a fresh process with
+    blocks of 128 rows (LTR_HEAD_BLOCK_ROWS, read once): 300 one-token-to-40-token requests, 820 labels on the tiny post-LN
+    model - labels and logits identical to the one-block run of this process, and the workspace of an 8,192-request call at
+    8,192 labels stays far below the 268 MB its logits alone would take."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+from util import synthetic_batch
+from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+from vllm_ltr_amd.scorer import HipOPTScorer
+spec = OPTSpec.tiny_post_ln(820)
+sc = HipOPTScorer(spec, seeded_checkpoint(spec, 16), 'cuda:0', 'f16')
+lens = np.random.RandomState(0).randint(1, 41, 300).tolist()
+ids, cu = synthetic_batch(spec, lens, 3)
+s, l = sc.score(ids, cu, return_logits=True)
+np.save(sys.argv[1], np.concatenate([s[:, None], l], 1))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for blk in ("0", "128"):
+        path = os.path.join(root, "gpurun_out", f"_head_blocks_{blk}.npy")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, LTR_HEAD_BLOCK_ROWS=blk))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs.append(np.load(path))
+        os.remove(path)
+    assert np.array_equal(outs[0], outs[1]) and np.isfinite(outs[0]).all()
+    assert (outs[0][:, 0] == outs[0][:, 1:1 + 512].argmax(-1)).all()     # (vocabulary 512 < 820 labels: logits_processor.py:68-70)
+    from vllm_ltr_amd import _lib
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.opt_125m(8192)
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
+    small = int(sc.lib.ltr_workspace_bytes(sc._h, _lib.LTR_WS_SCORE, 8192, 8192))
+    assert small < 200e6, small                              # (round 3: 268 MB of logits + the rest)
+
+
 @pytest.mark.parametrize("name,mode", [("opt125m", "f16"), ("opt125m", "f32"), ("opt350m", "f16")])
 def test_golden_true_shape(dev, name, mode):
     path = os.path.join(GOLDEN, f"score_{name}.npz")

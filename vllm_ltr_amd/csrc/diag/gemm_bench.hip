@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     return wp;
   };
   __half *w_qkv = weight(3 * H, H, 11), *w_out = weight(H, H, 12), *w_fc1 = weight(F, H, 13), *w_fc2 = weight(H, F, 14);
-  const size_t skb = (size_t)8 * (M < 32768 ? M : 32768) * H * 4;
+  const size_t skb = (size_t)4 * (M < 4800 ? M : 4800) * H * 4;       // what forward_chunk provides
   void* sk = alloc<char>(skb);
   float* vec = alloc<float>(4 * (size_t)F);
   fill_f32<<<64, 256>>>(vec, 4 * (size_t)F, 0.1f, 1.f, 8);
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   if (fold) { g_qkv.ln_stats_in = st1; g_qkv.ln_c = vec + F; g_qkv.ln_parts = H / 64; }
   g_out.a = AOp{a, a + (size_t)M * H}; g_out.w = w_out; g_out.bias = vec; g_out.resid = h; g_out.out_f32 = h; g_out.M = M; g_out.N = H; g_out.K = H;
   if (fold) { g_out.ln_gamma = vec + 2 * F; g_out.ln_out = AOp{a2, a2 + (size_t)M * H}; g_out.ln_stats_out = st2; }
-  if (M <= 32768) { g_out.splitk_ws = sk; g_out.splitk_ws_bytes = skb; g_fc2.splitk_ws = sk; g_fc2.splitk_ws_bytes = skb; }
+  { g_out.splitk_ws = sk; g_out.splitk_ws_bytes = skb; g_fc2.splitk_ws = sk; g_fc2.splitk_ws_bytes = skb; }
   g_fc1.a = AOp{a2, a2 + (size_t)M * H}; g_fc1.w = w_fc1; g_fc1.bias = vec; g_fc1.out_split = AOp{f, f + (size_t)M * F}; g_fc1.relu = 1;
   g_fc1.M = M; g_fc1.N = F; g_fc1.K = H; g_fc1.a_slab = g_fc1.out_slab = 1;
   if (fold) { g_fc1.ln_stats_in = st2; g_fc1.ln_c = vec + F; g_fc1.ln_parts = H / 64; }

@@ -101,6 +101,14 @@ constexpr int DEFAULT_CHUNK_TOKENS = 196608;
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// rows of padded class logits held at a time by the GEMM head (64 MB of f32 at most, at least 256 rows)
+inline int head_block_rows(int lpad) {
+  static const int forced = [] { const char* e = getenv("LTR_HEAD_BLOCK_ROWS"); return e ? atoi(e) : 0; }();   // tests: small blocks
+  if (forced >= 128) return forced / 128 * 128;
+  const int64_t r = ((int64_t)64 << 20) / ((int64_t)(lpad > 0 ? lpad : 1) * 4);
+  return (int)(r < 256 ? 256 : (r > (1 << 20) ? (1 << 20) : r)) / 128 * 128;
+}
+
 // passes of at most this many rows get the small-batch split-K scratch (launch_gemm decides per launch)
 constexpr int64_t SPLITK_MAX_ROWS = 4800;
 
@@ -154,7 +162,8 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, boo
     char* ho = (char*)take(Nc * H * esz);
     ws.head_op = AOp{ho, ho ? ho + Nc * H * 2 : nullptr};
     ws.head_feat = (char*)take(Nc * De * esz);
-    ws.head_logits = (float*)take((size_t)Nc * (head_lpad > 0 ? head_lpad : 1) * 4);
+    const size_t lrows = head_lpad > 0 ? (size_t)(Nc < head_block_rows(head_lpad) ? Nc : head_block_rows(head_lpad)) : 1;
+    ws.head_logits = (float*)take(lrows * (head_lpad > 0 ? head_lpad : 1) * 4);
   }
   if (d.weight_dtype == LTR_W_F16) {
     // up to 4 parts of [rows, H] f32, rows <= SPLITK_MAX_ROWS (beyond it the GEMMs have tiles enough without)
@@ -340,7 +349,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = ab; g.w = m->gemm_lw(L, LTR_WL_OUT_W); g.bias = (const float*)m->lw(L, LTR_WL_OUT_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = H;
-      if (Mr <= SPLITK_MAX_ROWS) { g.splitk_ws = ws.splitk; g.splitk_ws_bytes = ws.splitk_bytes; }
+      g.splitk_ws = ws.splitk; g.splitk_ws_bytes = ws.splitk_bytes;      // (launch_gemm uses it for small passes and for tail rows)
       // the LayerNorm that follows this residual add: pre-LN blocks LN2 (final_layer_norm), post-LN blocks LN1
       // (self_attn_layer_norm, opt.py:162-163)
       if (fold_here) {
@@ -377,7 +386,7 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       GemmArgs g{};
       g.a = fb; g.w = m->gemm_lw(L, LTR_WL_FC2_W); g.bias = (const float*)m->lw(L, LTR_WL_FC2_B);
       g.resid = hb; g.out_f32 = hb; g.M = Mr; g.N = H; g.K = F; g.a_slab = wd == LTR_W_F16;
-      if (Mr <= SPLITK_MAX_ROWS) { g.splitk_ws = ws.splitk; g.splitk_ws_bytes = ws.splitk_bytes; }
+      g.splitk_ws = ws.splitk; g.splitk_ws_bytes = ws.splitk_bytes;
       if (ln1_folded) {
         g.ln_gamma = d.pre_ln ? (const float*)m->lw(L + 1, LTR_WL_LN1_W) : (const float*)m->lw(L, LTR_WL_LN2_W);
         g.ln_out = ws.a; g.ln_stats_out = ws.stats1; g.err_flag = m->err_flag;
@@ -717,10 +726,19 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
           if ((rc = launch_gemm(wd, g, s))) return rc;
         }
         if (labels_gemm) {
-          GemmArgs g{};
-          g.a = feat; g.w = h->head_w; g.out_f32 = ws.head_logits; g.M = n; g.N = h->head_lpad; g.K = De; g.a_slab = 1;
-          if ((rc = launch_gemm(wd, g, s))) return rc;
-          if ((rc = launch_argmax_rows(ws.head_logits, h->head_lpad, n, n_cmp, d.num_labels, scores_dst, logits_dst, s))) return rc;
+          // the padded logits exist for HEAD_BLOCK_ROWS rows at a time (row windows of the label GEMM, argmax per block):
+          // 8,192 labels x 8,192 requests would otherwise add 268 MB to every scoring workspace
+          const int rb = head_block_rows(h->head_lpad);
+          for (int rw = 0; rw < n; rw += rb) {
+            const int nb = n - rw < rb ? n - rw : rb;
+            GemmArgs g{};
+            g.a = feat; g.w = h->head_w; g.N = h->head_lpad; g.K = De; g.a_slab = 1;
+            g.row0 = rw; g.M = nb; g.ldm = n;
+            g.out_f32 = ws.head_logits - (size_t)rw * h->head_lpad;          // (rows are indexed globally: block-local buffer)
+            if ((rc = launch_gemm(wd, g, s))) return rc;
+            if ((rc = launch_argmax_rows(ws.head_logits, h->head_lpad, nb, n_cmp, d.num_labels, scores_dst + rw,
+                                         logits_dst ? logits_dst + (size_t)rw * d.num_labels : nullptr, s))) return rc;
+          }
         } else {
           // few labels: dot products of the De-wide feature rows on the VALU (no LayerNorm, no projection left to do)
           rc = launch_pool_head(wd, (const float*)ws.head_feat, nullptr, 0, n, De, De, d.num_labels, n_cmp, nullptr, nullptr,

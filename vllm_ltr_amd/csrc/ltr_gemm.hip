@@ -84,6 +84,9 @@ struct Epilogue {
   int r_parts;
   const float* osc_a;     // LNS: max|x| of the operands' source tensors (the product is divided by their split scales)
   const float* osc_b;
+  // Row window (GemmArgs::row0 / ldm): the launch covers rows [row0, M) of tensors that have ldm rows - M is the END of
+  // the window, every row index is global; ldm is the pitch of the slab-major images and of the statistics arrays.
+  int row0, ldm;
 };
 
 // LNS rides on the consumer arithmetic v = (acc - mean c_n) rstd with mean = 0, c_n = 0, rstd = the output scale
@@ -239,7 +242,7 @@ template <int LNM, bool RLN>
 __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, float4 vb, float4 ra, float4 rb,
                                                const float4& bias_a, const float4& bias_b, const float4& lnv_a,
                                                const float4& lnv_b, const float2 st2, const float2 rst, int grow, int ccol,
-                                               int ccol_b, size_t o, int M, int lane, int piece64) {
+                                               int ccol_b, size_t o, int ldm, int lane, int piece64) {
   if (RLN) {   // (the two halves one after the other: the affine vectors of both at once cost 8 more live registers)
     {
       const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol);
@@ -276,7 +279,7 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
     __half h[8], l[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) split_f16(x[e], h[e], l[e]);
-    const size_t os = ep.out_slab ? slab_off(grow, ccol, M) : o;
+    const size_t os = ep.out_slab ? slab_off(grow, ccol, ldm) : o;
 #ifdef LTR_GEMM_NOSTORE   // diag: epilogue without its global stores (keeps the values alive through a never-true branch)
     if (h[0] == __half(12345.f) && l[7] == __half(54321.f))
 #endif
@@ -310,7 +313,7 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
     const uint4 hv = odd ? make_uint4(hr.x, hr.y, hk.x, hk.y) : make_uint4(hk.x, hk.y, hr.x, hr.y);
     const uint4 lv = odd ? make_uint4(lr.x, lr.y, lk.x, lk.y) : make_uint4(lk.x, lk.y, lr.x, lr.y);
     const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
-    const size_t oo = slab_off(grow, c0, M);
+    const size_t oo = slab_off(grow, c0, ldm);
     epi_store16((__half*)ep.ln_hi + oo, &hv);
     epi_store16((__half*)ep.ln_lo + oo, &lv);
     // (mean, M2) of this 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
@@ -322,7 +325,7 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float dd = x[e] - mu; q = fmaf(dd, dd, q); }
     q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-    if ((lane & 7) == 0) ep.stats_out[(size_t)piece64 * M + grow] = make_float2(mu, q);
+    if ((lane & 7) == 0) ep.stats_out[(size_t)piece64 * ldm + grow] = make_float2(mu, q);
   }
 }
 
@@ -342,13 +345,13 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     // blockIdx.y multiplies its K columns (K = the columns of ONE part; slab-major A) into its own partial output
     // (lda = the row pitch of a row-major A: its parts are column ranges)
     const size_t part = blockIdx.y;
-    const size_t aoff = ep.a_slab ? part * (size_t)K * M : part * (size_t)K;
+    const size_t aoff = ep.a_slab ? part * (size_t)K * ep.ldm : part * (size_t)K;
     a_hi += aoff; a_lo += aoff; w += part * (size_t)K * N;
-    ep.out_f32 += part * (size_t)M * N;
+    ep.out_f32 += part * (size_t)(M - ep.row0) * N;
   }
   int tm, tn;
   tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, gm);
-  const int m0 = tm * BM, n0 = tn * BN16;
+  const int m0 = ep.row0 + tm * BM, n0 = tn * BN16;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
       gw[i] = w + (size_t)min(n0 + wrow, N - 1) * BK16 + wc_log * 8;   // slab-major weight image
     }
   }
-  const size_t w_slab = (size_t)N * BK16, a_slab = ep.a_slab ? (size_t)M * BK16 : (size_t)BK16;
+  const size_t w_slab = (size_t)N * BK16, a_slab = ep.a_slab ? (size_t)ep.ldm * BK16 : (size_t)BK16;
   auto issue = [&](int stage, int k0) {
     __half* base = smem + stage * STAGE;
     const size_t ka = (size_t)(k0 / BK16) * a_slab, kw = (size_t)(k0 / BK16) * w_slab;
@@ -415,8 +418,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   if ((LNM == LNC || RLN) && tid < BM) {
     const int row = min(m0 + tid, M - 1);
     reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] =
-        RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, M, 1.f)
-            : combine_row_stats(ep.stats_in + row, ep.n_part, M, 1.f / LN_FOLD_SCALE);
+        RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f)
+            : combine_row_stats(ep.stats_in + row, ep.n_part, ep.ldm, 1.f / LN_FOLD_SCALE);
   }
   for (int kt = 0; kt < nk; ++kt) {
 #ifdef LTR_GEMM_TIMELINE
@@ -561,7 +564,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         const float4 xa = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
         const float4 xb = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
         epilogue_piece<LNM, false>(ep, xa, xb, z4, z4, z4, z4, ga, gb, make_float2(0.f, 0.f), make_float2(0.f, 0.f), gr[it],
-                                   ccol, ccol_b, (size_t)gr[it] * N + ccol, M, lane, tn * 4 + wc);
+                                   ccol, ccol_b, (size_t)gr[it] * N + ccol, ep.ldm, lane, tn * 4 + wc);
       }
     } else     if (ccol < N) {
       float4 va[2], vb[2], ra[2], rb[2];
@@ -591,7 +594,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         if (LNM == LNC || RLN) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
         if (LNM == LNS) st2 = out_scale_stat(ep);
         epilogue_piece<LNM, RLN>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, st2, gr[it], ccol,
-                                 ccol_b, o[it], M, lane, tn * 4 + wc);
+                                 ccol_b, o[it], ep.ldm, lane, tn * 4 + wc);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -682,9 +685,9 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
     // lda = the row pitch of a row-major A) into its own raw f32 partial [M, N]; splitk_epilogue_kernel adds the parts in
     // part order and runs the epilogue
     const size_t part = blockIdx.y;
-    const size_t aoff = ep.a_slab ? part * (size_t)K * M : part * (size_t)K;
+    const size_t aoff = ep.a_slab ? part * (size_t)K * ep.ldm : part * (size_t)K;
     a_hi += aoff; a_lo += aoff; w += part * (size_t)K * N;
-    ep.out_f32 += part * (size_t)M * N;
+    ep.out_f32 += part * (size_t)(M - ep.row0) * N;
   }
   // dynamic LDS on purpose: with a static array hipcc tracks the LDS-DMA stores against every ds_read and drains
   // vmcnt(0) in front of the first fragment read of each stage (ltr_attn.hip has the same note)
@@ -696,7 +699,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
 #endif
   int tm, tn;
   if (!xcd_tile(blockIdx.x, tiles_m, tiles_n, xmap, tm, tn)) return;
-  const int m0 = tm * BM_, n0 = tn * BN_;
+  const int m0 = ep.row0 + tm * BM_, n0 = tn * BN_;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / C::WN, wc = wave % C::WN;
@@ -715,7 +718,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
     if (r < C::PA) {
       const int g = r % (C::PA / 2);
       const int row = min(m0 + g * 16 + row16, M - 1);
-      gstep[p] = ep.a_slab ? (size_t)M * BK16 : (size_t)BK16;
+      gstep[p] = ep.a_slab ? (size_t)ep.ldm * BK16 : (size_t)BK16;
       gsrc[p] = (r < C::PA / 2 ? a_hi : a_lo) + (size_t)row * (ep.a_slab ? BK16 : lda) + c_log * 8 + sl * gstep[p];
     } else {
       const int g = r - C::PA;
@@ -743,8 +746,8 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
     if (st < nst) issue(st, st);
   if ((LNM == LNC || RLN) && tid < BM_) {     // (mean, M2) pieces of the row -> (mean, rstd [/ scale]); see the large-tile kernel
     const int row = min(m0 + tid, M - 1);
-    s_stat[tid] = RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, M, 1.f)
-                      : combine_row_stats(ep.stats_in + row, ep.n_part, M, 1.f / LN_FOLD_SCALE);
+    s_stat[tid] = RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f)
+                      : combine_row_stats(ep.stats_in + row, ep.n_part, ep.ldm, 1.f / LN_FOLD_SCALE);
   }
   for (int kt = 0; kt < nst; ++kt) {
     // stage kt has landed once at most the younger stages' pieces (NP per stage and wave) are outstanding
@@ -852,7 +855,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
       float2 st2 = make_float2(0.f, 0.f);
       if (LNM == LNC || RLN) st2 = s_stat[srow];
       if (LNM == LNS) st2 = out_scale_stat(ep);
-      epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, M, lane,
+      epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, st2, st2, grow, ccol, ccol_b, o, ep.ldm, lane,
                                tn * P64 + pc);
     }
   }
@@ -876,19 +879,20 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
   const int lane = threadIdx.x & 63, l8 = gid & 7;
   const int p64 = N / 64;
   const int idx = gid >> 3;
-  const int grow = idx / p64, pc = idx % p64;
+  const int grow = ep.row0 + idx / p64, pc = idx % p64;
   const bool live = grow < M;            // (whole 8-lane groups are live or not: the shuffles inside epilogue_piece stay inside a group)
   const bool wide = ep.out_hi == nullptr;
   const int ecol = l8 * (wide ? 4 : 8), ecol_b = wide ? ecol + 32 : ecol + 4;
   const int ccol = pc * 64 + ecol, ccol_b = pc * 64 + ecol_b;
   if (!live) return;
   const size_t o = (size_t)grow * N + ccol;
-  const size_t pstride = (size_t)M * N;
-  float4 va = *reinterpret_cast<const float4*>(partial + o);
-  float4 vb = *reinterpret_cast<const float4*>(partial + o + (ccol_b - ccol));
+  const size_t po = (size_t)(grow - ep.row0) * N + ccol;          // the partials hold the rows of the window only
+  const size_t pstride = (size_t)(M - ep.row0) * N;
+  float4 va = *reinterpret_cast<const float4*>(partial + po);
+  float4 vb = *reinterpret_cast<const float4*>(partial + po + (ccol_b - ccol));
   for (int p = 1; p < parts; ++p) {
-    const float4 a = *reinterpret_cast<const float4*>(partial + p * pstride + o);
-    const float4 b = *reinterpret_cast<const float4*>(partial + p * pstride + o + (ccol_b - ccol));
+    const float4 a = *reinterpret_cast<const float4*>(partial + p * pstride + po);
+    const float4 b = *reinterpret_cast<const float4*>(partial + p * pstride + po + (ccol_b - ccol));
     va.x += a.x; va.y += a.y; va.z += a.z; va.w += a.w;
     vb.x += b.x; vb.y += b.y; vb.z += b.z; vb.w += b.w;
   }
@@ -910,8 +914,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
     lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
   }
   float2 rst = make_float2(0.f, 0.f);
-  if (RLN) rst = combine_row_stats(ep.r_stats + grow, ep.r_parts, M, 1.f);
-  epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, rst, rst, grow, ccol, ccol_b, o, M, lane, pc);
+  if (RLN) rst = combine_row_stats(ep.r_stats + grow, ep.r_parts, ep.ldm, 1.f);
+  epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, rst, rst, grow, ccol, ccol_b, o, ep.ldm, lane, pc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1108,9 +1112,15 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   }
   const int bn = wdtype == LTR_W_F16 ? BN16 : BN;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + bn - 1) / bn;
-  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, g.M, g.N, g.relu, g.a_slab, g.out_slab,
+  if ((g.row0 || g.ldm) && (wdtype != LTR_W_F16 || g.row0 < 0 || (g.ldm && g.ldm < g.row0 + g.M) || g.split_k > 1)) {
+    set_error("gemm: a row window needs F16 mode, 0 <= row0, row0 + M <= ldm and no split_k");
+    return LTR_E_INVAL;
+  }
+  const int Mend = g.row0 + g.M, ldm = g.ldm ? g.ldm : Mend;       // the kernels' M is the END row of the window
+  Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, Mend, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
-              g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts, g.osc_a, g.osc_b};
+              g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts, g.osc_a, g.osc_b,
+              g.row0, ldm};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : (g.osc_a ? LNS : LN_NONE));
   if (g.osc_a && (wdtype != LTR_W_F16 || !g.osc_b || g.ln_gamma || g.ln_stats_in || g.rln_stats)) {
     set_error("gemm: scaled operands (osc_a / osc_b) need F16 mode, both scales and no LayerNorm fold");
@@ -1182,7 +1192,9 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     bool rln_k = rln;
     if (parts > 1) {
       epk = Epilogue{};
-      epk.out_f32 = (float*)g.splitk_ws; epk.M = g.M; epk.N = g.N; epk.a_slab = g.a_slab;
+      // raw partials [parts][window rows][N]; the kernels index rows globally: bias the base by the window's first row
+      epk.out_f32 = (float*)g.splitk_ws - (size_t)g.row0 * g.N; epk.M = Mend; epk.N = g.N; epk.a_slab = g.a_slab;
+      epk.row0 = g.row0; epk.ldm = ldm;
       lnm_k = LN_NONE; rln_k = false;
     }
     const int kpart = g.K / parts;
@@ -1190,10 +1202,10 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
       const unsigned nthreads = (unsigned)g.M * (unsigned)(g.N / 8);
       const dim3 rgrid((nthreads + 255) / 256);
       const float* part = (const float*)g.splitk_ws;
-      if (rln) { if (lnm == LNP) splitk_epilogue_kernel<LNP, true><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep);
-                 else splitk_epilogue_kernel<LN_NONE, true><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep); }
-      else if (lnm == LNP) splitk_epilogue_kernel<LNP, false><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep);
-      else splitk_epilogue_kernel<LN_NONE, false><<<rgrid, 256, 0, s>>>(part, parts, g.M, g.N, ep);
+      if (rln) { if (lnm == LNP) splitk_epilogue_kernel<LNP, true><<<rgrid, 256, 0, s>>>(part, parts, Mend, g.N, ep);
+                 else splitk_epilogue_kernel<LN_NONE, true><<<rgrid, 256, 0, s>>>(part, parts, Mend, g.N, ep); }
+      else if (lnm == LNP) splitk_epilogue_kernel<LNP, false><<<rgrid, 256, 0, s>>>(part, parts, Mend, g.N, ep);
+      else splitk_epilogue_kernel<LN_NONE, false><<<rgrid, 256, 0, s>>>(part, parts, Mend, g.N, ep);
       LTR_LAUNCH_CHECK();
       return LTR_OK;
     };
@@ -1235,7 +1247,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     }();                                                                                                                   \
     (void)attr_ok;                                                                                                         \
     gemm_f16s_small_kernel<LN, RL, BMv, BNv, WMv, WNv, SLv, STv><<<sgrid, Cfg::NW * 64, Cfg::LDS_BYTES, s>>>(               \
-        (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, kpart, g.K, tm_, tn_, xm, epk);          \
+        (const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N, kpart, g.K, tm_, tn_, xm, epk);         \
   } while (0)
 #define LTR_SMALL_LN(...)                                                                                                  \
   do {                                                                                                                     \
@@ -1258,16 +1270,38 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
         return parts > 1 ? finish_split() : LTR_OK;
       }
     }
+    // ---- tail rows (LTR_GEMM_TAIL=1, off by default: measured, no net gain).  The 128 x 256 kernel runs 512 tiles at a time
+    // (two workgroups per CU): 543 tiles - fc2 of a 23,078-row pass - look like two rounds for 6 % more work than one.  With
+    // the switch on, the rows beyond the last full round go to a second launch_gemm on a row window, where the small-batch
+    // kernels take them.  Measured at 23,078 rows (profiles/r04_small_gemm_lab.txt): fc2 210 -> 187 us, out_proj 86 -> 81, but
+    // QKV 188 -> 193 and fc1 174 -> 190: the 31 tiles of a "second round" run alone on the chip at twice the per-tile speed of
+    // a full round, so the tail costs far less than a round, and the extra launch eats what is left.
+    static const int tail_on = [] { const char* e = getenv("LTR_GEMM_TAIL"); return e ? atoi(e) : 0; }();
+    if (tail_on && split <= 1 && parts == 1 && force_cfg == -2) {
+      const int tiles = tiles_m * tiles_n, rounds = tiles / 512;
+      if (rounds >= 1 && tiles % 512) {
+        const int full_row_tiles = (rounds * 512) / tiles_n;
+        const int R = full_row_tiles * BM, tail = g.M - R;
+        const int tail_tiles = tiles - full_row_tiles * tiles_n;
+        if (R > 0 && tail > 0 && tail <= (can_split ? 4800 : 3000) && tail_tiles <= 320) {
+          GemmArgs g1 = g, g2 = g;
+          g1.M = R; g1.ldm = ldm;
+          g2.row0 = g.row0 + R; g2.M = tail; g2.ldm = ldm;
+          const int rc = launch_gemm(wdtype, g1, s);
+          return rc ? rc : launch_gemm(wdtype, g2, s);
+        }
+      }
+    }
     if (parts > 1) {                     // the 128 x 256 kernel, split: raw partials, then the epilogue kernel
       grid.y = parts;
-      gemm_f16s_kernel<LN_NONE, false><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N,
+      gemm_f16s_kernel<LN_NONE, false><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N,
                                                            kpart, g.K, tiles_m, tiles_n, gm, epk);
       LTR_LAUNCH_CHECK();
       return finish_split();
     }
     grid.y = split;
 #define LTR_BIG_LAUNCH(LN, RL)                                                                                             \
-  gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, g.M, g.N, \
+  gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N, \
                                                 g.K / split, g.K, tiles_m, tiles_n, gm, ep)
     if (rln) { if (lnm == LNP) LTR_BIG_LAUNCH(LNP, true); else LTR_BIG_LAUNCH(LN_NONE, true); }
     else if (lnm == LNP) LTR_BIG_LAUNCH(LNP, false);

@@ -89,6 +89,12 @@ struct GemmArgs {
   // with splitk_epilogue_kernel, which adds the parts in part order (deterministic) and runs the epilogue.
   void* splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
+  // Row window (F16 mode): the launch computes rows [row0, row0 + M) of tensors that have `ldm` rows (0: row0 + M).  Every
+  // pointer is the base of its WHOLE tensor (row-major tensors are indexed by global row, slab-major images and the
+  // statistics arrays have pitch ldm).  launch_gemm uses it itself to give the rows that would start one more, mostly
+  // empty, round of 128 x 256 tiles to the small-batch kernels ("tail rows").
+  int row0 = 0;
+  int ldm = 0;
 };
 
 // launchers (each in its own .hip file)
