@@ -2,9 +2,14 @@
 // computation, element by element (links libltr_hip.so, calls ltr::launch_gemm directly).
 // Built by vllm_ltr_amd/csrc/build.py into csrc/build/gemm_check and run by tests/test_gpu_gemm_epilogue.py
 // (NaN-safe comparisons: a stale-register store can leave NaN bit patterns behind).
+//   gemm_check M N K [row0 rows]     row0 / rows: run both GEMMs on the ROW WINDOW [row0, row0 + rows) of the M-row tensors
+//   (GemmArgs::row0 / ldm) - rows outside the window must come back untouched.  The producer gets the split-K scratch the
+//   scoring path provides, so launch_gemm's own choice (tile configuration, K parts) is what is checked; LTR_GEMM_FORCE_CFG /
+//   LTR_GEMM_FORCE_SPLIT / LTR_GEMM_TAIL in the environment select the other paths.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <hip/hip_fp16.h>
 #include "ltr_internal.h"
@@ -16,6 +21,9 @@ template <class T> std::vector<T> host(const T* p, size_t n) { std::vector<T> v(
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 200, N = argc > 2 ? atoi(argv[2]) : 128, K = argc > 3 ? atoi(argv[3]) : 128;
+  const int row0 = argc > 5 ? atoi(argv[4]) : 0, rows = argc > 5 ? atoi(argv[5]) : M;
+  if (row0 < 0 || rows <= 0 || row0 + rows > M) { printf("bad window\n"); return 2; }
+  auto inside = [&](int m) { return m >= row0 && m < row0 + rows; };
   srand(1);
   std::vector<float> a((size_t)M * K), resid((size_t)M * N), bias(N), gamma(N);
   std::vector<__half> ahi(a.size()), alo(a.size()), w((size_t)N * K);
@@ -33,8 +41,12 @@ int main(int argc, char** argv) {
   __half* d_ln; (void)hipMalloc(&d_ln, (size_t)M * N * 4); (void)hipMemset(d_ln, 0xff, (size_t)M * N * 4);
   float2* d_stats; (void)hipMalloc(&d_stats, (size_t)(N / 64) * M * 8); (void)hipMemset(d_stats, 0xff, (size_t)(N / 64) * M * 8);
   GemmArgs g{};
-  g.a = AOp{d_ahi, d_alo}; g.w = d_wp; g.bias = d_bias; g.resid = d_out; g.out_f32 = d_out; g.M = M; g.N = N; g.K = K;
+  g.a = AOp{d_ahi, d_alo}; g.w = d_wp; g.bias = d_bias; g.resid = d_out; g.out_f32 = d_out; g.M = rows; g.N = N; g.K = K;
+  g.row0 = row0; g.ldm = M;
   g.ln_gamma = d_gamma; g.ln_out = AOp{d_ln, d_ln + (size_t)M * N}; g.ln_stats_out = d_stats;
+  const size_t skb = (size_t)4 * (rows < 4800 ? rows : 4800) * N * 4;      // what forward_chunk hands to the residual producers
+  void* d_sk; (void)hipMalloc(&d_sk, skb); (void)hipMemset(d_sk, 0xff, skb);
+  g.splitk_ws = d_sk; g.splitk_ws_bytes = skb;
   int rc = launch_gemm(LTR_W_F16, g, 0);
   (void)hipDeviceSynchronize();
   printf("LNP rc=%d\n", rc);
@@ -49,13 +61,18 @@ int main(int argc, char** argv) {
       for (int k = 0; k < K; ++k) s += ((double)__half2float(ahi[(size_t)m * K + k]) + (double)__half2float(alo[(size_t)m * K + k])) * (double)__half2float(w[(size_t)n * K + k]);
       s += bias[n] + resid[(size_t)m * N + n];
       ref[(size_t)m * N + n] = s;
-      if (!(fabs(out[(size_t)m * N + n] - s) <= 1e-4)) { if (bad_out++ < 5) printf("out[%d,%d] = %g want %g\n", m, n, out[(size_t)m * N + n], s); }
       const size_t so = ((size_t)(n >> 5) * M + m) * 32 + (n & 31);
+      if (!inside(m)) {     // outside the window: the residual row and the 0xff fill must still be there
+        unsigned short raw; memcpy(&raw, &ln[so], 2);
+        if (out[(size_t)m * N + n] != resid[(size_t)m * N + n] || raw != 0xffff) { if (bad_out++ < 5) printf("row %d outside the window was written\n", m); }
+        continue;
+      }
+      if (!(fabs(out[(size_t)m * N + n] - s) <= 1e-4)) { if (bad_out++ < 5) printf("out[%d,%d] = %g want %g\n", m, n, out[(size_t)m * N + n], s); }
       const double got = (double)__half2float(ln[so]) + (double)__half2float(ln[(size_t)M * N + so]);
       const double want = s * gamma[n] * 16.0;
       if (!(fabs(got - want) <= 1e-3 * (1 + fabs(want)))) { if (bad_ln++ < 12 || (bad_ln % 97) == 0) printf("a'[%d,%d] = %g (hi %g lo %g) want %g\n", m, n, got, __half2float(ln[so]), __half2float(ln[(size_t)M * N + so]), want); }
     }
-    for (int p = 0; p < N / 64; ++p) {
+    for (int p = 0; p < N / 64 && inside(m); ++p) {
       double mu = 0, q = 0;
       for (int c = 0; c < 64; ++c) mu += ref[(size_t)m * N + p * 64 + c];
       mu /= 64;
@@ -80,7 +97,9 @@ int main(int argc, char** argv) {
   launch_ln_fold_coeff(d_w2, d_gamma, d_beta, d_b2, N2, N, d_c, d_d, 0);
   __half* d_o2; (void)hipMalloc(&d_o2, (size_t)M * N2 * 4);
   GemmArgs c{};
-  c.a = g.ln_out; c.w = d_w2p; c.bias = d_d; c.out_split = AOp{d_o2, d_o2 + (size_t)M * N2}; c.M = M; c.N = N2; c.K = N;
+  (void)hipMemset(d_o2, 0xff, (size_t)M * N2 * 4);
+  c.a = g.ln_out; c.w = d_w2p; c.bias = d_d; c.out_split = AOp{d_o2, d_o2 + (size_t)M * N2}; c.M = rows; c.N = N2; c.K = N;
+  c.row0 = row0; c.ldm = M;
   c.a_slab = 1; c.ln_stats_in = d_stats; c.ln_c = d_c; c.ln_parts = N / 64;
   rc = launch_gemm(LTR_W_F16, c, 0);
   (void)hipDeviceSynchronize();
@@ -88,6 +107,13 @@ int main(int argc, char** argv) {
   auto o2 = host(d_o2, (size_t)M * N2 * 2);
   int bad_c = 0;
   for (int m = 0; m < M; ++m) {
+    if (!inside(m)) {
+      for (int n2 = 0; n2 < N2; ++n2) {
+        unsigned short raw; memcpy(&raw, &o2[(size_t)m * N2 + n2], 2);
+        if (raw != 0xffff) { if (bad_c++ < 5) printf("lnc row %d outside the window was written\n", m); break; }
+      }
+      continue;
+    }
     double mu = 0, var = 0;
     for (int n = 0; n < N; ++n) mu += ref[(size_t)m * N + n];
     mu /= N;
