@@ -16,6 +16,10 @@ def worker(rank, world, port):
     local = torch.arange(counts[rank], dtype=torch.float32, device=dev) + 100 * rank
     out = torch.empty(sum(counts), dtype=torch.float32, device=dev)
     g = gather_scores(local, counts, out=out)
+    # the form ShardedScorer uses when a collective timeout is set: async op + a host-side wait with a deadline
+    import datetime
+    g2 = gather_scores(local, counts, wait=lambda w: w.wait(datetime.timedelta(seconds=30)))
+    assert torch.equal(g, g2)
     t = torch.tensor([rank], dtype=torch.int32, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     f = torch.tensor([1.5 + rank], dtype=torch.float64, device=dev)
