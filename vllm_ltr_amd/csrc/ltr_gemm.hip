@@ -649,7 +649,8 @@ template <int BM_, int BN_, int WM_, int WN_, int SL_, int SSTAGES> struct Small
   static_assert(SL * (PA + PW) % NW == 0 && PIECES >= 1 && PIECES <= 8, "piece map: 1-8 DMA instructions per wave and stage");
   static_assert(SSTAGES >= 3 && SSTAGES <= 8, "counted vmcnt waits cover up to 6 stages in flight");
   static_assert((size_t)EROWS * CLDS * 4 <= (size_t)SSTAGES * STAGE_H * 2, "epilogue tile must fit the ring");
-  static_assert(BM_ % (WM * 16) == 0 && BN_ % (WN * 16) == 0 && (EROWS * BN_ / 8) % (NW * 64) == 0, "tile / wave grid mismatch");
+  static_assert(BM_ % (WM * 16) == 0 && BN_ % (WN * 16) == 0 &&
+                ((EROWS * BN_ / 8) % (NW * 64) == 0 || (NW * 64) % (EROWS * BN_ / 8) == 0), "tile / wave grid mismatch");
 };
 
 // Workgroup -> tile map of the small-tile kernels: the 8 XCDs (block b runs on XCD b % 8, private 4 MiB L2s) form an
@@ -821,8 +822,10 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
             s_c[(lrow0 + i * 16 + 4 * (lane >> 4) + e) * C::CLDS + wc * (C::TJ * 16) + j * 16 + (lane & 15)] = acc[i][j][e];
     }
     __syncthreads();
+    constexpr int NPIECE = C::EROWS * BN_ / 8;                         // (row, 8 columns) pieces of this pass
 #pragma unroll
-    for (int pi = 0; pi < C::EROWS * BN_ / 8 / (C::NW * 64); ++pi) {
+    for (int pi = 0; pi < (NPIECE + C::NW * 64 - 1) / (C::NW * 64); ++pi) {
+      if (NPIECE < C::NW * 64 && tid >= NPIECE) continue;              // more threads than pieces (many-wave configurations)
       const int idx = (pi * (C::NW * 64) + tid) >> 3;                // (row, piece) index; the 8 lanes of a piece are consecutive
       const int lrow = idx / P64, pc = idx % P64;
       const int srow = rbase + lrow;                                 // row inside the tile
@@ -1173,7 +1176,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     static const int force_cfg = [] { const char* e = getenv("LTR_GEMM_FORCE_CFG"); return e ? atoi(e) : -2; }();       // diag: -1 big, 0, 1
     static const int force_split = [] { const char* e = getenv("LTR_GEMM_FORCE_SPLIT"); return e ? atoi(e) : 0; }();  // diag: parts (1 = off)
     // tile menu of the small-batch kernel: BM x BN (waves, K stage, ring) - see the instantiation list below
-    static const int CFG_BM[6] = {32, 64, 128, 32, 64, 64}, CFG_BN[6] = {64, 128, 256, 128, 64, 256};
+    static const int CFG_BM[9] = {32, 64, 128, 32, 64, 64, 128, 64, 32}, CFG_BN[9] = {64, 128, 256, 128, 64, 256, 256, 128, 64};
     // ---- small-batch split-K.  A narrow output (out_proj, fc2: N = H) of a small batch has few tiles (M = 262 rows:
     // 9 x 12 = 108 on 256 CUs) and, for fc2, a long K: the workgroups that exist each stream hundreds of KB through one
     // ring at the rate ONE CU pulls from the fabric.  Cutting K into `parts` multiplies the workgroups and divides the
@@ -1182,7 +1185,8 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     const bool can_split = split <= 1 && g.splitk_ws && lnm != LNC && lnm != LNS && g.out_f32 && !g.out_split.hi && !g.relu;
     SmallChoice ch = split > 1 ? SmallChoice{-1, 1} : choose_small(g, can_split);
     int cfg = ch.cfg;
-    if (split <= 1 && (force_cfg == -1 || ((force_cfg == 0 || force_cfg == 1 || force_cfg == 5) && g.K % 64 == 0 && g.N % CFG_BN[force_cfg] == 0)))
+    if (split <= 1 && (force_cfg == -1 || ((force_cfg == 0 || force_cfg == 1 || (force_cfg >= 5 && force_cfg <= 8)) && g.K % 64 == 0 &&
+                                          g.N % CFG_BN[force_cfg] == 0)))
       cfg = force_cfg;
     int parts = can_split ? ch.parts : 1;
     if (can_split && force_split > 0) parts = force_split;
@@ -1263,7 +1267,13 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
         // ring of four (SmallCfg<128, 256, 2, 4, 1, 4>), 3 = 32 x 128 (<32, 128, 2, 2, 2, 4>), 4 = 64 x 64 (<64, 64, 2, 2, 2, 4>))
         if (cfg == 0) LTR_SMALL_LN(32, 64, 2, 2, 2, 4);
         else if (cfg == 1) LTR_SMALL_LN(64, 128, 2, 4, 2, 4);
-        else LTR_SMALL_LN(64, 256, 2, 4, 1, 4);
+        else if (cfg == 5) LTR_SMALL_LN(64, 256, 2, 4, 1, 4);
+#ifdef LTR_GEMM_LAB_WAVES   // lab: the same tiles with twice the waves (does a CU's LDS-DMA rate scale with the waves that issue it?)
+        else if (cfg == 6) LTR_SMALL_LN(128, 256, 4, 4, 1, 4);
+        else if (cfg == 7) LTR_SMALL_LN(64, 128, 4, 4, 2, 4);
+        else if (cfg == 8) LTR_SMALL_LN(32, 64, 2, 4, 2, 4);
+#endif
+        else { set_error("gemm: tile configuration %d is not built", cfg); return LTR_E_INVAL; }
 #undef LTR_SMALL_LN
 #undef LTR_SMALL_LAUNCH
         LTR_LAUNCH_CHECK();
