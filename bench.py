@@ -534,13 +534,15 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic_src = tj.get("source")
-                if traffic_src and traffic_src.get("kernel_sha16") == sha:
+                # (taken on THESE kernel sources and on THIS workload: the PMC passes run the default 125m / sharegpt / 8k call)
+                wl = f"{args.model}/{args.profile}/{n_local}"
+                if traffic_src and traffic_src.get("kernel_sha16") == sha and traffic_src.get("workload", "125m/sharegpt/8192") == wl:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 pass
             try:
                 pj = json.load(open(ppath))
-                if (pj.get("source") or {}).get("kernel_sha16") == sha:
+                if (pj.get("source") or {}).get("kernel_sha16") == sha and (pj.get("source") or {}).get("workload", "125m/sharegpt/8192") == wl:
                     pmc = pj.get("gemm_f16s_kernel")
             except Exception:
                 pass
@@ -566,7 +568,7 @@ def main():
                     "traffic_ratio": traffic * launches_per_step / comp if traffic and comp else None,
                     "traffic_note": "fabric-side (TCC_EA requests, calibrated): Infinity-Cache hits included - an upper bound on DRAM traffic",
                     "traffic_source": traffic_src if traffic is not None else
-                    {"stale": True, "reason": "profiles/gemm_traffic.json was not taken on the current kernel sources",
+                    {"stale": True, "reason": "profiles/gemm_traffic.json was not taken on the current kernel sources and workload",
                      "file": traffic_src, "current_kernel_sha16": sha},
                     # launches of THIS kernel only (the 128 x 256-tile one: the rocprofv3 row of the same name); the compact
                     # last-token rows of each pass run on the small-batch kernels, timed apart as kernels.gemm_small

@@ -28,7 +28,9 @@ def source_stamp():
     for rel in ("vllm_ltr_amd/csrc/ltr_gemm.hip", "vllm_ltr_amd/csrc/ltr_api.hip"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
-    return dict(tag=os.environ.get("LTR_PROFILE_TAG", ""), kernel_sha16=h.hexdigest()[:16])
+    # the passes of diag/refresh_profiles.sh run the default bench workload: bench.py quotes them for that workload only
+    return dict(tag=os.environ.get("LTR_PROFILE_TAG", ""), kernel_sha16=h.hexdigest()[:16],
+                workload=os.environ.get("LTR_PROFILE_WORKLOAD", "125m/sharegpt/8192"))
 
 CALIB_BYTES = 4 << 30
 # which calibrated access form dominates each production kernel's reads
