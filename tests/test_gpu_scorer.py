@@ -124,7 +124,9 @@ np.save(sys.argv[1], np.concatenate([s[:, None], l], 1))
     sc = HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
     small = int(sc.lib.ltr_workspace_bytes(sc._h, _lib.LTR_WS_SCORE, 8192, 8192))
     print(f"workspace of an 8,192-request / 8,192-token call at 8,192 labels: {small / 1e6:.0f} MB")
-    assert small < 520e6, small      # 253 MB of per-token buffers + 64 MB of logits + ... (round 3: + 268 MB of logits)
+    # one lane: 253 MB of per-token buffers + 64 MB of logits + ... = 455 MB (round 3: + 268 MB of logits); an 8,192-token call
+    # is in the two-lane range (ltr_api.hip run_forward): two halves of <= 5,122 tokens, each with its own 64-MB block
+    assert small < 700e6, small
 
 
 @pytest.mark.parametrize("name,mode", [("opt125m", "f16"), ("opt125m", "f32"), ("opt350m", "f16")])

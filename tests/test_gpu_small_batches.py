@@ -59,6 +59,45 @@ def test_scores_do_not_depend_on_the_batch_size_regime(model):
         assert np.abs(want - whole[idx]).max() <= TOL
 
 
+@pytest.mark.parametrize("model", ["125m", "tiny_post_ln"])
+def test_two_lanes_score_what_the_two_halves_score_alone(model):
+    """A call of 1,200 ... 49,152 tokens runs as two request-aligned halves on two streams (ltr_api.hip run_forward, "lanes";
+    include/ltr_hip.h).  Each half is the call one would make for it alone: the scores must be BIT-identical to scoring the
+    halves in two calls (which, below 1,200 tokens each, run on one lane), the call must be counted as a two-lane call, and
+    a following call on the same stream must see the finished scores (the join)."""
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = {"125m": OPTSpec.opt_125m, "tiny_post_ln": OPTSpec.tiny_post_ln}[model]()
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, 11), "cuda:0", "f16")
+    tiny = model.startswith("tiny")
+    lens = bench_lengths(24, seed=9, mu=64.0).clip(1, 150 if tiny else 400)
+    while lens.sum() < 1500:
+        lens = np.concatenate([lens, lens[:4]])
+    lens = lens[: int(np.searchsorted(np.cumsum(lens), 2000)) + 1]
+    ids, cu = synthetic_batch(spec, lens.tolist(), 5)
+    T = int(cu[-1])
+    assert 1200 <= T < 2400 + int(lens.max())
+    # the library's cut: the request boundary closest to T / 2 (the first one at or past it, or the one before)
+    half = T // 2
+    r_mid = 1
+    while r_mid + 1 < len(lens) and cu[r_mid + 1] <= half:
+        r_mid += 1
+    if r_mid + 1 < len(lens) and cu[r_mid + 1] - half < half - cu[r_mid]:
+        r_mid += 1
+    assert cu[r_mid] < 1200 and T - cu[r_mid] < 1200          # each half alone: one lane
+    before = sc.lane_calls()
+    whole = sc.score(ids, cu)
+    assert sc.lane_calls() == before + 1, "the call did not run on two lanes"
+    a = sc.score(*_sub(ids, cu, list(range(r_mid))))
+    b = sc.score(*_sub(ids, cu, list(range(r_mid, len(lens)))))
+    assert sc.lane_calls() == before + 1
+    assert np.array_equal(whole, np.concatenate([a, b]))
+    for _ in range(3):                                            # deterministic, and nothing of a previous call leaks
+        assert np.array_equal(sc.score(ids, cu), whole)
+    if not tiny:
+        want = OracleOPTScorer(spec, seeded_checkpoint(spec, 11)).score(*_sub(ids, cu, [0, r_mid - 1, r_mid, len(lens) - 1]))
+        assert np.abs(want - whole[[0, r_mid - 1, r_mid, len(lens) - 1]]).max() <= TOL
+
+
 def test_single_request_latency_budget():
     """One arrival scored and the 8k queue re-ranked: the call a live scheduler step makes.  The 128 x 256 kernel needed
     2.1 ms for it (49 GEMM launches of 37 us on a dozen CUs); the bound here is loose (boxes differ), the number is

@@ -20,7 +20,7 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 
 # every symbol include/ltr_hip.h declares (tests check the library exports them all)
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
-           "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
+           "ltr_set_chunk_tokens", "ltr_lane_calls", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
@@ -105,6 +105,8 @@ def _load() -> C.CDLL:
     lib.ltr_workspace_bytes.argtypes = [vp, i32, i64, i64]
     lib.ltr_workspace_bytes.restype = sz
     lib.ltr_set_chunk_tokens.argtypes = [vp, i32]
+    lib.ltr_lane_calls.argtypes = [vp]
+    lib.ltr_lane_calls.restype = C.c_int64
     lib.ltr_score.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.ltr_forward_hidden.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.ltr_embed_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]

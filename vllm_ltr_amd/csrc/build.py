@@ -62,7 +62,9 @@ def build(force: bool = False) -> str:
 # element-level checker of the GEMM's LayerNorm-fold epilogues (diag/gemm_check.hip), run by the -m gpu tests
 TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip"),
          # times the four dense layers of a decoder layer at M rows through launch_gemm (A/B of tile / split-K / XCD-map choices)
-         "gemm_bench": os.path.join("diag", "gemm_bench.hip")}
+         "gemm_bench": os.path.join("diag", "gemm_bench.hip"),
+         # the GEMMs of two half batches on two streams against the whole batch on one (the "lanes" of run_forward)
+         "lanes_probe": os.path.join("diag", "lanes_probe.hip")}
 
 
 def _build_tools(force: bool) -> None:

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -57,7 +58,7 @@ struct ltr_model {
   float* fold = nullptr;
   std::vector<const float*> fold_c_qkv, fold_d_qkv, fold_c_fc1, fold_d_fc1;
   // F16 mode: the LAST layer's qkv_proj as two images, q rows [0, H) and k | v rows [H, 3H) - a scoring call needs
-  // that layer's Q for the last token of each request only (forward_chunk; LTR_NO_LASTQ=1 switches it off)
+  // that layer's Q for the last token of each request only (ChunkRun::layer; LTR_NO_LASTQ=1 switches it off)
   bool lastq = false;
   const void* last_q_w = nullptr;
   const void* last_kv_w = nullptr;
@@ -67,7 +68,16 @@ struct ltr_model {
   const void* proj_out_w = nullptr;
   const void* head_w = nullptr;
   int head_lpad = 0;
+  // Lanes (run_forward): a second stream + fork / join events, so that the two halves of a mid-sized batch run concurrently.
+  // lane_mu serialises the ENQUEUE section of calls that use them (calls that find it taken run on one lane).
+  hipStream_t lane_stream = nullptr;
+  hipEvent_t lane_fork = nullptr, lane_join = nullptr;
+  std::mutex lane_mu;
+  std::atomic<int64_t> lane_calls{0};
   ~ltr_model() {
+    if (lane_stream) (void)hipStreamDestroy(lane_stream);
+    if (lane_fork) (void)hipEventDestroy(lane_fork);
+    if (lane_join) (void)hipEventDestroy(lane_join);
     if (packed) (void)hipFree(packed);
     if (fold) (void)hipFree(fold);
     if (err_flag) (void)hipFree(err_flag);
@@ -111,6 +121,16 @@ inline int head_block_rows(int lpad) {
 
 // passes of at most this many rows get the small-batch split-K scratch (launch_gemm decides per launch)
 constexpr int64_t SPLITK_MAX_ROWS = 4800;
+
+// Lanes (run_forward): batches of 1,200 .. 49,152 tokens run as two halves on two streams.  LTR_LANES: 0 never, 1 (default)
+// in that range, 2 whenever the batch has two requests (lab); LTR_LANES_MIN / LTR_LANES_MAX move the range.  Measured
+// (profiles/r04_lanes_lab.txt): -4 ... -11 % per call between 1.4k and 44k tokens (OPT-125m and OPT-350m), +-1 % from 64k up.
+inline int lanes_mode() { static const int v = [] { const char* e = getenv("LTR_LANES"); return e ? atoi(e) : 1; }(); return v; }
+inline bool lanes_for_tokens(int64_t T) {
+  static const int64_t lo = [] { const char* e = getenv("LTR_LANES_MIN"); return e ? atoll(e) : 1200; }();
+  static const int64_t hi = [] { const char* e = getenv("LTR_LANES_MAX"); return e ? atoll(e) : 49152; }();
+  return lanes_mode() >= 2 || (lanes_mode() == 1 && T >= lo && T <= hi);
+}
 
 // workspace carve-up for one chunk of at most Tc tokens / Nc requests
 struct Workspace {
@@ -210,31 +230,52 @@ struct ProfScope {
   }
 };
 
-// one request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch
-int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev, int N_total, int r0, int r1, int t0,
-                  int t1, int n_layers, const Workspace& ws, double sum_l2, bool prune_last, const float** h_final,
-                  hipStream_t s) {
-  const ltr_model_desc& d = m->d;
-  const int wd = d.weight_dtype;
-  const int H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim;
-  const int Tc = t1 - t0, nreq = r1 - r0;
-  int rc;
-  // --- embedding (opt.py:241-245)
-  const double wbytes = wd == LTR_W_F16 ? 2.0 : 4.0;
+// One request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch - as a stepper (begin, then one call per
+// decoder layer), so that run_forward can issue the layers of two independent chunks ALTERNATELY onto two streams ("lanes").
+struct ChunkRun {
+  const ltr_model* m;
+  const int64_t* ids;
+  const int32_t* cu_dev;
+  int N_total, r0, r1, t0, t1, n_layers;
+  Workspace ws;
+  double sum_l2;
+  bool prune_last;
+  hipStream_t s;
+  // derived / state
+  const ltr_model_desc& d;
+  const int wd, H, F, De, Tc, nreq;
+  int nl = 0;
+  bool fold = false, ln1_folded = false;
   // rows / buffers of the part of a layer after attention: all Tc token rows, except in the
   // last layer of a scoring call where only the nreq last-token rows are carried on (below)
-  int Mr = Tc;
-  float* hb = ws.h;
-  AOp ab = ws.a, fb = ws.f;
-  auto gemm = [&](const GemmArgs& g) {
+  int Mr;
+  float* hb;
+  AOp ab, fb;
+  ChunkRun(const ltr_model* m_, const int64_t* ids_, const int32_t* cu_dev_, int N_total_, int r0_, int r1_, int t0_, int t1_,
+           int n_layers_, const Workspace& ws_, double sum_l2_, bool prune_last_, hipStream_t s_)
+      : m(m_), ids(ids_), cu_dev(cu_dev_), N_total(N_total_), r0(r0_), r1(r1_), t0(t0_), t1(t1_), n_layers(n_layers_), ws(ws_),
+        sum_l2(sum_l2_), prune_last(prune_last_), s(s_), d(m_->d), wd(m_->d.weight_dtype), H(m_->d.hidden_size),
+        F(m_->d.ffn_dim), De(m_->d.word_embed_proj_dim), Tc(t1_ - t0_), nreq(r1_ - r0_), Mr(t1_ - t0_), hb(ws_.h), ab(ws_.a),
+        fb(ws_.f) {}
+  int gemm(const GemmArgs& g) {
     // the dominant kernel (128 x 256 tiles) and the small-batch kernels are timed as separate classes
     ProfScope p(m, wd == LTR_W_F16 && gemm_small_config(g) >= 0 ? LTR_K_GEMM_SMALL : LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
     return launch_gemm(wd, g, s);
-  };
-  auto lnorm = [&](int rows, const float* x, const float* gw_, const float* gb_, float* of, AOp oo) {
+  }
+  int lnorm(int rows, const float* x, const float* gw_, const float* gb_, float* of, AOp oo) {
     ProfScope p(m, LTR_K_LN, (double)rows * H * (of ? 12.0 : 8.0), s);   // f32 row in, operand row (+f32 row) out
     return launch_layernorm(wd, x, gw_, gb_, rows, H, of, oo, s);
-  };
+  }
+  const float* h_final() const { return hb; }   // ws.h, or the compact last-token rows when the last layer was pruned
+  int begin();
+  int layer(int L);
+};
+
+int ChunkRun::begin() {
+  int rc;
+
+  // --- embedding (opt.py:241-245)
+  const double wbytes = wd == LTR_W_F16 ? 2.0 : 4.0;
   {
     ProfScope p(m, LTR_K_EMBED, (double)Tc * (8.0 + (De + H) * wbytes + H * 4.0), s);
     rc = launch_embed_gather(wd, ids, cu_dev, N_total, Tc, t0, m->gw(LTR_WT_EMBED_TOKENS), De, d.vocab_size,
@@ -250,13 +291,17 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
   if (!d.pre_ln) {   // post-LN blocks consume h itself as the first GEMM operand
     if ((rc = launch_to_operand(wd, ws.h, Tc, H, ws.a, s))) return rc;
   }
-  const int nl = n_layers < 0 ? d.num_layers : (n_layers < d.num_layers ? n_layers : d.num_layers);
+  nl = n_layers < 0 ? d.num_layers : (n_layers < d.num_layers ? n_layers : d.num_layers);
   // LayerNorm fold (ltr_gemm.hip): out_proj / fc2 emit the operand and the row statistics of the LayerNorm that
   // follows them, QKV / fc1 finish it in their epilogue.  `ln1_folded`: this layer's QKV operand (ws.a) and
   // ws.stats1 were written by the previous layer's fc2.
-  const bool fold = m->ln_fold;
-  bool ln1_folded = false;
-  for (int L = 0; L < nl; ++L) {
+  fold = m->ln_fold;
+  ln1_folded = false;
+  return LTR_OK;
+}
+
+int ChunkRun::layer(const int L) {
+  int rc;
     // --- attention half (opt.py:152-163)
     if (d.pre_ln && !ln1_folded) {
       rc = lnorm(Tc, ws.h, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), nullptr, ws.a);
@@ -401,8 +446,6 @@ int forward_chunk(const ltr_model* m, const int64_t* ids, const int32_t* cu_dev,
       rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), hb, ab);
       if (rc) return rc;
     }
-  }
-  *h_final = hb;   // ws.h, or the compact last-token rows when the last layer was pruned
   return LTR_OK;
 }
 
@@ -497,6 +540,14 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
     return LTR_E_NOMEM;
   }
   { const char* e = getenv("LTR_DEBUG_ATTN_VALU"); m->dbg_attn_valu = e && e[0] == '1'; }
+  if (lanes_mode() > 0 && desc->weight_dtype == LTR_W_F16) {     // second lane for mid-sized batches (run_forward); optional
+    if (hipStreamCreateWithFlags(&m->lane_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->lane_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (m->lane_stream) { (void)hipStreamDestroy(m->lane_stream); m->lane_stream = nullptr; }
+    }
+  }
   m->wg = m->w;
   if (desc->weight_dtype == LTR_W_F16) {
     // one-time re-layout of the dense-layer weights into the GEMM kernel's slab-major image
@@ -565,7 +616,7 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
     const char* e = getenv("LTR_NO_LN_FOLD");
     const size_t H = desc->hidden_size, F = desc->ffn_dim;
     // pre-LN (125m): LN1 rides on QKV, LN2 on fc1.  Post-LN (350m): this layer's LN1 (after the attention residual)
-    // rides on fc1, the PREVIOUS layer's LN2 on QKV; the residuals are rebuilt by the RLN epilogue (forward_chunk).
+    // rides on fc1, the PREVIOUS layer's LN2 on QKV; the residuals are rebuilt by the RLN epilogue (ChunkRun::layer).
     m->ln_fold = desc->weight_dtype == LTR_W_F16 && H % 64 == 0 && desc->num_layers > 0 && !(e && e[0] == '1');
     if (m->ln_fold) {
       const size_t per_layer = 2 * (3 * H + F);
@@ -619,6 +670,8 @@ int ltr_status(ltr_handle h, void* stream) {
   return LTR_OK;
 }
 
+int64_t ltr_lane_calls(ltr_handle h) { return h ? h->lane_calls.load(std::memory_order_relaxed) : 0; }
+
 int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens) {
   if (!h || chunk_tokens < 0) { set_error("ltr_set_chunk_tokens: bad argument"); return LTR_E_INVAL; }
   h->chunk_tokens = chunk_tokens == 0 ? DEFAULT_CHUNK_TOKENS : chunk_tokens;
@@ -630,7 +683,17 @@ size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
   if (kind == LTR_WS_SCORE && h) {
     int64_t Tc = T < chunk_cap(h) ? T : chunk_cap(h);
     int64_t Nc = N < Tc ? N : Tc;
-    return carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold, head_mode(h)).bytes;
+    const size_t one = carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold, head_mode(h)).bytes;
+    if (h->lane_stream && T <= chunk_cap(h) && N >= 2 && lanes_for_tokens(T)) {
+      // two lanes: the cut is the request boundary closest to the middle, so a half holds at most T / 2 tokens plus half
+      // a request of maximal length - and at most as many requests as tokens
+      int64_t Th = T / 2 + (h->d.pos_rows - 2 + 1) / 2 + 1;
+      if (Th > T) Th = T;
+      const int64_t Nh = N - 1 < Th ? N - 1 : Th;
+      const size_t two = 2 * align_up(carve(h->d, Th, Nh > 0 ? Nh : 1, nullptr, h->ln_fold, head_mode(h)).bytes);
+      return two > one ? two : one;
+    }
+    return one;
   }
   return 0;
 }
@@ -660,31 +723,14 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
   // chunk budget from the workspace actually provided
   int64_t Tc_cap = chunk_cap(h) < T ? chunk_cap(h) : T;
   while (Tc_cap > 1 && carve(d, Tc_cap, Tc_cap < N ? Tc_cap : N, nullptr, h->ln_fold, head_mode(h)).bytes > ws_bytes) Tc_cap /= 2;
-  int r0 = 0;
-  while (r0 < N) {
-    int r1 = r0;
-    while (r1 < N && (int64_t)cu[r1 + 1] - cu[r0] <= Tc_cap) {
-      const int L = cu[r1 + 1] - cu[r1];
-      if (L <= 0) { set_error("ltr_score: request %d has length %d (empty prompts are not schedulable)", r1, L); return LTR_E_INVAL; }
-      if (L > max_pos) { set_error("ltr_score: request %d has %d tokens > max positions %d (truncate first, aux_llm_engine.py:365-369)", r1, L, max_pos); return LTR_E_INVAL; }
-      ++r1;
-    }
-    if (r1 == r0) {
-      const int L = cu[r0 + 1] - cu[r0];
-      if (L <= 0) { set_error("ltr_score: request %d has length %d", r0, L); return LTR_E_INVAL; }
-      set_error("ltr_score: workspace of %zu bytes cannot hold request %d (%d tokens)", ws_bytes, r0, L);
-      return LTR_E_NOMEM;
-    }
-    const int t0 = cu[r0], t1 = cu[r1];
-    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace, h->ln_fold, head_mode(h));
-    if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
-    if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
-    double sum_l2 = 0.0;
-    for (int r = r0; r < r1; ++r) { const double L = cu[r + 1] - cu[r]; sum_l2 += L * L; }
-    const bool prune = !hidden_out && d.num_layers > 0;
-    const float* h_final = ws.h;
-    rc = forward_chunk(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, sum_l2, prune, &h_final, s);
-    if (rc) return rc;
+  // what follows the decoder layers of a chunk: the hidden states out, or final LayerNorm / project_out / head -> scores
+  auto finish_chunk = [&](ChunkRun& c) -> int {
+    const Workspace& ws = c.ws;
+    hipStream_t s = c.s;
+    const int r0 = c.r0, r1 = c.r1, t0 = c.t0, t1 = c.t1;
+    const bool prune = c.prune_last;
+    const float* h_final = c.h_final();
+    int rc = LTR_OK;
     if (hidden_out) {
       LTR_HIP_CHECK(hipMemcpyAsync(hidden_out, ws.h, (size_t)(t1 - t0) * d.hidden_size * 4, hipMemcpyDeviceToDevice, s));
     } else {
@@ -747,6 +793,73 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
         }
       }
     }
+    return LTR_OK;
+  };
+  int r0 = 0;
+  while (r0 < N) {
+    int r1 = r0;
+    while (r1 < N && (int64_t)cu[r1 + 1] - cu[r0] <= Tc_cap) {
+      const int L = cu[r1 + 1] - cu[r1];
+      if (L <= 0) { set_error("ltr_score: request %d has length %d (empty prompts are not schedulable)", r1, L); return LTR_E_INVAL; }
+      if (L > max_pos) { set_error("ltr_score: request %d has %d tokens > max positions %d (truncate first, aux_llm_engine.py:365-369)", r1, L, max_pos); return LTR_E_INVAL; }
+      ++r1;
+    }
+    if (r1 == r0) {
+      const int L = cu[r0 + 1] - cu[r0];
+      if (L <= 0) { set_error("ltr_score: request %d has length %d", r0, L); return LTR_E_INVAL; }
+      set_error("ltr_score: workspace of %zu bytes cannot hold request %d (%d tokens)", ws_bytes, r0, L);
+      return LTR_E_NOMEM;
+    }
+    const int t0 = cu[r0], t1 = cu[r1];
+    const bool prune = !hidden_out && d.num_layers > 0;
+    auto sum_sq = [&](int a_, int b_) { double v = 0.0; for (int r = a_; r < b_; ++r) { const double L = cu[r + 1] - cu[r]; v += L * L; } return v; };
+    // ---- lanes: a mid-sized batch (tens to hundreds of arrivals of a scheduler step) as TWO request-aligned halves on two
+    // streams, their layers issued alternately.  In that regime a launch has too few tiles for the chip, or a last round
+    // that is mostly empty, and its prologue / epilogue are exposed (profiles/r04_small_gemm_lab.txt); the halves are
+    // independent (a request never reads another request's state), so one half's under-filled launches run beside the
+    // other's.  Each half is exactly the call one would make for it alone (same kernels, same results).
+    int r_mid = -1;
+    if (!hidden_out && r0 == 0 && r1 == N && N >= 2 && h->lane_stream && lanes_for_tokens(t1 - t0)) {
+      const int64_t half = (t1 - t0) / 2;
+      r_mid = 1;
+      while (r_mid + 1 < N && cu[r_mid + 1] - t0 <= half) ++r_mid;              // first cut at or past the middle ...
+      if (r_mid + 1 < N && (cu[r_mid + 1] - t0) - half < half - (cu[r_mid] - t0)) ++r_mid;   // ... or the one before, whichever is closer
+    }
+    std::unique_lock<std::mutex> lane_lock(h->lane_mu, std::defer_lock);
+    if (r_mid > 0 && !lane_lock.try_lock()) r_mid = -1;
+    if (r_mid > 0) {
+      const int tm_ = cu[r_mid];
+      Workspace wa = carve(d, tm_ - t0, r_mid - r0, workspace, h->ln_fold, head_mode(h));
+      Workspace wb = carve(d, t1 - tm_, r1 - r_mid, (char*)workspace + align_up(wa.bytes), h->ln_fold, head_mode(h));
+      if (align_up(wa.bytes) + wb.bytes <= ws_bytes) {
+        hipStream_t s2 = h->lane_stream;
+        LTR_HIP_CHECK(hipEventRecord(h->lane_fork, s));
+        LTR_HIP_CHECK(hipStreamWaitEvent(s2, h->lane_fork, 0));
+        ChunkRun ca(h, token_ids, cu_seqlens, N, r0, r_mid, t0, tm_, n_layers, wa, sum_sq(r0, r_mid), prune, s);
+        ChunkRun cb(h, token_ids, cu_seqlens, N, r_mid, r1, tm_, t1, n_layers, wb, sum_sq(r_mid, r1), prune, s2);
+        rc = ca.begin();
+        if (!rc) rc = cb.begin();
+        for (int L = 0; !rc && L < ca.nl; ++L) { rc = ca.layer(L); if (!rc) rc = cb.layer(L); }
+        if (!rc) rc = finish_chunk(ca);
+        if (!rc) rc = finish_chunk(cb);
+        // join even after an error: the caller's stream must not run ahead of work already queued on the lane
+        (void)hipEventRecord(h->lane_join, s2);
+        (void)hipStreamWaitEvent(s, h->lane_join, 0);
+        if (rc) return rc;
+        h->lane_calls.fetch_add(1, std::memory_order_relaxed);
+        r0 = r1;
+        continue;
+      }
+    }
+    if (lane_lock.owns_lock()) lane_lock.unlock();
+    Workspace ws = carve(d, t1 - t0, r1 - r0, workspace, h->ln_fold, head_mode(h));
+    if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
+    if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }
+    ChunkRun c(h, token_ids, cu_seqlens, N, r0, r1, t0, t1, n_layers, ws, sum_sq(r0, r1), prune, s);
+    rc = c.begin();
+    for (int L = 0; !rc && L < c.nl; ++L) rc = c.layer(L);
+    if (rc) return rc;
+    if ((rc = finish_chunk(c))) return rc;
     r0 = r1;
   }
   return LTR_OK;

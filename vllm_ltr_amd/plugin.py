@@ -290,7 +290,8 @@ class MI355XRanker:
                               mean_ms_per_call=st["rank_seconds"] * 1e3 / st["rank_calls"] if st["rank_calls"] else None,
                               last=pct(self._rank_ms)),
                     live_slots=self._live_slots, queue_length=self._n_members,
-                    sharded=self._sharded is not None)
+                    sharded=self._sharded is not None,
+                    two_lane_calls=self.scorer.lane_calls() if hasattr(self.scorer, "lane_calls") else 0)
 
     def _check_status(self) -> None:
         """Raise where the reference's F.embedding raises (a token id outside the vocabulary), or when the residual

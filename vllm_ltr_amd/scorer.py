@@ -103,6 +103,10 @@ class HipOPTScorer:
         _lib.check(self.lib.ltr_set_chunk_tokens(self._h, int(n)), "ltr_set_chunk_tokens")
         self._ws = None
 
+    def lane_calls(self) -> int:
+        """Scoring calls on this handle that ran as two halves on two streams (include/ltr_hip.h "Lanes")."""
+        return int(self.lib.ltr_lane_calls(self._h))
+
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.ltr_profile_enable(self._h, 1 if on else 0), "ltr_profile_enable")
 
