@@ -54,6 +54,14 @@ int main(int argc, char** argv) {
     return wp;
   };
   __half *w_qkv = weight(3 * H, H, 11), *w_out = weight(H, H, 12), *w_fc1 = weight(F, H, 13), *w_fc2 = weight(H, F, 14);
+  // BENCH_ROTATE=R: R copies of every weight matrix, launch r uses copy r % R - as the R layers of a forward do (the same
+  // weights every launch stay in the XCDs' L2s: 1.2-4.7 MB each; a forward streams 85 MB of them)
+  const int rot = getenv("BENCH_ROTATE") ? atoi(getenv("BENCH_ROTATE")) : 1;
+  std::vector<__half*> r_qkv{w_qkv}, r_out{w_out}, r_fc1{w_fc1}, r_fc2{w_fc2};
+  for (int i = 1; i < rot; ++i) {
+    r_qkv.push_back(weight(3 * H, H, 11 + 10 * i)); r_out.push_back(weight(H, H, 12 + 10 * i));
+    r_fc1.push_back(weight(F, H, 13 + 10 * i)); r_fc2.push_back(weight(H, F, 14 + 10 * i));
+  }
   const size_t skb = (size_t)4 * (M < 4800 ? M : 4800) * H * 4;       // what forward_chunk provides
   void* sk = alloc<char>(skb);
   float* vec = alloc<float>(4 * (size_t)F);
@@ -110,7 +118,10 @@ int main(int argc, char** argv) {
   printf("layer     %8.1f us  %7.1f TFLOP/s   (M=%d H=%d F=%d fold=%d)\n", sum * 1e3, fl / sum / 1e9, M, H, F, (int)fold);
   {  // the four launches back to back, as the model issues them (launch gaps included)
     (void)hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r) for (auto& it : items) launch_gemm(LTR_W_F16, *it.g, 0);
+    for (int r = 0; r < reps; ++r) {
+      g_qkv.w = r_qkv[r % rot]; g_out.w = r_out[r % rot]; g_fc1.w = r_fc1[r % rot]; g_fc2.w = r_fc2[r % rot];
+      for (auto& it : items) launch_gemm(LTR_W_F16, *it.g, 0);
+    }
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("sequence  %8.1f us per layer (4 GEMMs back to back)\n", ms / reps * 1e3);
