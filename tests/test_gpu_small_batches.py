@@ -98,6 +98,56 @@ def test_two_lanes_score_what_the_two_halves_score_alone(model):
         assert np.abs(want - whole[[0, r_mid - 1, r_mid, len(lens) - 1]]).max() <= TOL
 
 
+def test_concurrent_callers_on_one_handle():
+    """Two host threads score different batches on ONE handle at the same time, each with its own workspace, output and
+    stream (include/ltr_hip.h allows it; the engine's async loop and a warm-up thread can meet like this).  The handle owns
+    one second lane: the caller that finds it taken runs on one lane.  Every call must return what it returns alone."""
+    import threading
+    from vllm_ltr_amd import _lib
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.tiny_pre_ln()
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, 3), "cuda:0", "f16")
+    dev = torch.device("cuda:0")
+    jobs = []
+    for j in range(2):
+        lens = bench_lengths(60, seed=20 + j, mu=40.0).clip(1, 150)
+        ids, cu = synthetic_batch(spec, lens.tolist(), 7 + j)
+        assert 1200 <= int(cu[-1]) <= 49152                     # two-lane range
+        want = sc.score(ids, cu)
+        need = int(sc.lib.ltr_workspace_bytes(sc._h, _lib.LTR_WS_SCORE, len(lens), int(cu[-1])))
+        jobs.append(dict(ids=torch.from_numpy(ids).to(dev), cu_d=torch.from_numpy(cu).to(dev), cu=np.ascontiguousarray(cu, np.int32),
+                         ws=torch.empty(need, dtype=torch.uint8, device=dev), out=torch.empty(len(lens), device=dev),
+                         stream=torch.cuda.Stream(dev), want=want, max_len=int(lens.max())))
+    torch.cuda.synchronize()
+    errors = []
+
+    def run(job, reps):
+        try:
+            for _ in range(reps):
+                job["out"].fill_(float("nan"))
+                with torch.cuda.stream(job["stream"]):
+                    rc = sc.lib.ltr_score(sc._h, job["ids"].data_ptr(), job["cu_d"].data_ptr(), job["cu"].ctypes.data,
+                                          len(job["cu"]) - 1, int(job["cu"][-1]), job["max_len"], job["out"].data_ptr(), None,
+                                          job["ws"].data_ptr(), job["ws"].numel(), job["stream"].cuda_stream)
+                    assert rc == 0, rc
+                job["stream"].synchronize()
+                got = job["out"].cpu().numpy()
+                # (a call that found the lane taken ran its GEMMs at other row counts: the small-batch contract, not bits)
+                assert np.abs(got - job["want"]).max() <= 3e-6 * max(1.0, float(np.abs(job["want"]).max()))
+        except BaseException as e:      # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    before = sc.lane_calls()
+    th = [threading.Thread(target=run, args=(j, 40)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    print(f"80 concurrent calls, {sc.lane_calls() - before} of them on two lanes")
+    sc.check_status()
+
+
 def test_single_request_latency_budget():
     """One arrival scored and the 8k queue re-ranked: the call a live scheduler step makes.  The 128 x 256 kernel needed
     2.1 ms for it (49 GEMM launches of 37 us on a dozen CUs); the bound here is loose (boxes differ), the number is
