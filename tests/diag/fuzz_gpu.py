@@ -55,7 +55,7 @@ while time.time() - t0 < budget:
     # ---- scorer on random ragged batches with tiny chunks (pass boundaries)
     if n_rank % 4 == 0:
         spec, ck, orc = scorers[r.randint(0, len(scorers))]
-        lens = r.randint(1, 150, r.randint(1, 40)).tolist()
+        lens = r.randint(1, 150, r.randint(1, 40 if r.rand() < 0.5 else 160)).tolist()
         ids, cu = synthetic_batch(spec, lens, int(r.randint(0, 10**6)))
         hs = HipOPTScorer(spec, ck, device=dev, weight_dtype="f16", chunk_tokens=int(r.choice([0, 160, 256, 1000])))
         got = hs.score(ids, cu); want = orc.score(ids, cu)
