@@ -18,6 +18,11 @@ the ``ran`` set, the budget-walk inputs and the starvation counters after the ag
   (``plugin.py``; device pieces replaced by recording doubles - there is no GPU here): pins the attribute surface
   ``install()`` touches (scheduler.py:290-331,1101-1105,1337-1365) and must reproduce run a's orders and counters.
 
+``--config 3`` writes ``tests/golden/config3_opt350m_128.npz`` instead: BASELINE config 3's predictor (OPT-350m: post-LN blocks,
+project_in / project_out, 24 layers) on 128 requests of the LMSYS-like length profile (``synthetic_queue(spec, 128, seed 0,
+"lmsys")``), runs ``a`` (starv 200 / period 10) and ``b`` (starv 6 / period 2, tight budget) as above - the second model
+family through the reference's own Scheduler + predictor.
+
 Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
 """
 from __future__ import annotations
@@ -216,7 +221,39 @@ def recording_ranker(schedule_type, aux, log):
     return RecordingRanker()
 
 
+def main_config3():
+    """OPT-350m, 128 LMSYS-like requests: runs a and b through the reference's own Scheduler + predictor."""
+    mg._init_dist()
+    torch.set_num_threads(os.cpu_count())
+    n = 128
+    spec = OPTSpec.opt_350m()
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = synthetic_queue(spec, n, seed=0, profile="lmsys")
+    out = dict(ids=ids.astype(np.int32), cu_seqlens=cu, seed=np.int64(0))
+    arrive_a = np.zeros(n, np.int32)
+    arrive_a[32:] = 1 + (np.arange(n - 32) // 8)               # 32 at step 0, then 8 per step (steps 1..12)
+    pred = RefPredictor(spec, ckpt)
+    t0 = time.time()
+    s_a, sgs_a, rec_a = run("a", "opt-xxx-starv200-period10", pred, ids, cu, arrive_a, 40, 2048, 256, out)
+    scores = np.array([g.aux_model_score for g in sgs_a], np.float64)
+    assert np.isfinite(scores).all() and len(pred.calls) == 13 and sum(map(len, pred.calls)) == n
+    out["ref_score"] = scores.astype(np.float32)
+    assert np.array_equal(out["ref_score"].astype(np.float64), scores)
+    out["a_aux_calls"] = np.array([len(c) for c in pred.calls], np.int32)
+    print(f"config 3 run a: T = {int(cu[-1])}, {len(pred.calls)} predictor calls, {pred.seconds:.1f} s in the reference "
+          f"predictor ({n / pred.seconds:.1f} req/s on {os.cpu_count()} threads), total {time.time()-t0:.1f} s; score range "
+          f"[{scores.min():.4f}, {scores.max():.4f}], smallest gap between sorted scores {np.diff(np.sort(scores)).min():.3e}")
+    table = {str(i): float(out["ref_score"][i]) for i in range(n)}
+    arrive_b = np.sort(np.random.RandomState(5).randint(0, 16, n)).astype(np.int32)
+    run("b", "opt-xxx-starv6-period2", ScoreTable(table), ids, cu, arrive_b, 48, 768, 16, out)
+    path = os.path.join(GOLD, "config3_opt350m_128.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":
+        return main_config3()
     mg._init_dist()
     torch.set_num_threads(os.cpu_count())
     spec = OPTSpec.opt_125m()

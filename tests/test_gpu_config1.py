@@ -1,4 +1,5 @@
-"""-m gpu: BASELINE config 1 (OPT-125m predictor, 256-request queue, T = 23,078) END TO END against the reference's own run.
+"""-m gpu: BASELINE config 1 (OPT-125m predictor, 256-request queue, T = 23,078) and config 3's predictor (OPT-350m - post-LN
+blocks, project_in / project_out - on 128 LMSYS-like requests, T = 25,532) END TO END against the reference's own runs.
 
 ``tests/golden/config1_opt125m_256.npz`` (oracle/make_config1_golden.py) was recorded from the reference's own
 ``Scheduler`` (scheduler.py:969-1000,1101-1373) with the reference's own fp32 ``OPTForSequenceClassification`` standing
@@ -25,16 +26,26 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def z():
-    return np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
+CASES = {"config1": ("config1_opt125m_256.npz", OPTSpec.opt_125m), "config3": ("config3_opt350m_128.npz", OPTSpec.opt_350m)}
 
 
-@pytest.fixture(scope="module")
-def scorer():
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request):
     from vllm_ltr_amd.scorer import HipOPTScorer
-    spec = OPTSpec.opt_125m()
-    return HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
+    name, mk = CASES[request.param]
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    spec = mk()
+    return request.param, z, HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", "f16")
+
+
+@pytest.fixture(scope="module")
+def z(case):
+    return case[1]
+
+
+@pytest.fixture(scope="module")
+def scorer(case):
+    return case[2]
 
 
 class ReplayScheduler:
@@ -104,7 +115,7 @@ def _replay(z, tag, scorer, preset_scores):
 def test_config1_hip_scores_vs_reference_predictor(z, scorer):
     got = scorer.score(z["ids"].astype(np.int64), z["cu_seqlens"])
     err = np.abs(got - z["ref_score"])
-    print(f"config 1: HIP predictor vs the reference's fp32 predictor over 256 requests (23,078 tokens): "
+    print(f"HIP predictor vs the reference's fp32 predictor over {len(got)} requests ({int(z['cu_seqlens'][-1]):,} tokens): "
           f"max|d| = {err.max():.3e}, rms {np.sqrt((err ** 2).mean()):.3e}")
     assert err.max() <= TOL
 
@@ -126,15 +137,15 @@ def test_config1_end_to_end_order_hip_scores_hip_sort(z, scorer, tag):
     err = float(np.abs(hip - ref).max())
     assert err <= TOL
     if tag == "a":                                             # one predictor call per arrival batch, like the reference's run
-        assert ranker.stats["aux_calls"] == len(z["a_aux_calls"]) and ranker.stats["requests_scored"] == 256
-    n_pairs = n_adj = n_disc = n_steps_diff = 0
+        assert ranker.stats["aux_calls"] == len(z["a_aux_calls"]) and ranker.stats["requests_scored"] == len(ref)
+    n_pairs = n_disc = n_steps_diff = 0
+    distinct = set()
     worst = 0.0
     for step, got in enumerate(orders):
         want = z[f"{tag}_order"][step]
         want = want[want >= 0].tolist()
         n = len(want)
         n_pairs += n * (n - 1) // 2
-        n_adj += max(n - 1, 0)
         if got == want:
             continue
         n_steps_diff += 1
@@ -144,8 +155,10 @@ def test_config1_end_to_end_order_hip_scores_hip_sort(z, scorer, tag):
         n_disc += len(d)
         for a, b, gap in d:
             worst = max(worst, gap)
+            distinct.add((min(a, b), max(a, b)))
             assert gap <= 2 * err, (tag, step, a, b, gap, err)
-    print(f"config 1 run {tag}: END-TO-END order (HIP scores -> HIP sort) vs the reference's order over {len(orders)} steps: "
-          f"{n_disc} discordant pairs of {n_pairs} ({n_steps_diff} steps differ), largest reference-score gap among them "
+    print(f"run {tag}: END-TO-END order (HIP scores -> HIP sort) vs the reference's order over {len(orders)} steps: "
+          f"{n_disc} discordant pairs of {n_pairs} ({n_steps_diff} steps differ; {len(distinct)} distinct request pairs), largest reference-score gap among them "
           f"{worst:.3e}; max|score error| {err:.3e}; closest pair of reference scores {np.diff(np.sort(ref)).min():.3e}")
-    assert n_disc <= max(1, n_adj // 1000)                     # fewer than 0.1 % of the adjacent pairs
+    # (a near-tie is the same two requests step after step while both wait: config 3 has one pair 2.7e-6 apart)
+    assert len(distinct) <= max(1, len(ref) // 100)

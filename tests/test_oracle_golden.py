@@ -218,18 +218,27 @@ def _config1():
     return np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
 
 
-def test_config1_oracle_scores_and_end_to_end_order():
-    """The oracle predictor on config 1's whole queue (256 requests, 23,078 tokens) against the scores the reference's
-    own fp32 OPTForSequenceClassification produced INSIDE the reference's own Scheduler run - and the END-TO-END order:
-    every step's order from the oracle's scores + the oracle's sort against the order the reference scheduler saw."""
-    z = _config1()
-    spec = OPTSpec.opt_125m()
+def _config3():
+    return np.load(os.path.join(GOLDEN, "config3_opt350m_128.npz"), allow_pickle=False)
+
+
+RECORDED = {"config1": (_config1, OPTSpec.opt_125m), "config3": (_config3, OPTSpec.opt_350m)}
+
+
+@pytest.mark.parametrize("which", list(RECORDED))
+def test_config1_oracle_scores_and_end_to_end_order(which):
+    """The oracle predictor on config 1's whole queue (256 requests, 23,078 tokens; config 3's predictor: OPT-350m on 128
+    LMSYS-like requests, 25,532 tokens) against the scores the reference's own fp32 OPTForSequenceClassification produced
+    INSIDE the reference's own Scheduler run - and the END-TO-END order: every step's order from the oracle's scores + the
+    oracle's sort against the order the reference scheduler saw."""
+    z = RECORDED[which][0]()
+    spec = RECORDED[which][1]()
     orc = OracleOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])))
     ids, cu = z["ids"].astype(np.int64), z["cu_seqlens"]
     got = orc.score_packed(ids, cu)
     ref = z["ref_score"]
     err = float(np.abs(got - ref).max())
-    print(f"config 1: oracle vs reference predictor over 256 requests: max|d| = {err:.3e}")
+    print(f"{which}: oracle vs reference predictor over {len(ref)} requests: max|d| = {err:.3e}")
     assert err <= 1e-5
     n_disc = 0
     for tag in ("a", "b"):
@@ -247,11 +256,12 @@ def test_config1_oracle_scores_and_end_to_end_order():
             rs.age_update(alive, [reqs[int(i)] for i in np.nonzero(z[f"{tag}_ran"][step])[0]])
             st = z[f"{tag}_states"][step]
             assert all((r.pri, r.idle, r.runs) == tuple(st[int(r.request_id)]) for r in alive), (tag, step)
-    print(f"config 1: {n_disc} discordant pairs between the oracle's end-to-end order and the reference's over both runs")
+    print(f"{which}: {n_disc} discordant pairs between the oracle's end-to-end order and the reference's over both runs")
 
 
-def test_config1_literal_sort_on_reference_scores_is_bit_identical():
-    z = _config1()
+@pytest.mark.parametrize("which", list(RECORDED))
+def test_config1_literal_sort_on_reference_scores_is_bit_identical(which):
+    z = RECORDED[which][0]()
     ref = z["ref_score"]
     for tag in ("a", "b"):
         starv, period = int(z[f"{tag}_starv"]), int(z[f"{tag}_period"])
