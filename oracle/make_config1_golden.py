@@ -23,6 +23,11 @@ project_in / project_out, 24 layers) on 128 requests of the LMSYS-like length pr
 "lmsys")``), runs ``a`` (starv 200 / period 10) and ``b`` (starv 6 / period 2, tight budget) as above - the second model
 family through the reference's own Scheduler + predictor.
 
+``--config tpt`` writes ``tests/golden/config1_tpt_class82.npz``: config 1's queue (the ids live in ``config1_opt125m_256.npz``)
+scheduled by the reference under ``tpt`` - the class-mode predictor (``OPTSpec.opt_125m(82)``: ``compute_logits`` returns
+``float(argmax)``, opt.py:394-395) and the order ``(-score, request_id)`` with STRING request ids (scheduler.py:938-948): 82
+labels over 256 requests, i.e. ties everywhere, broken by ``"10" < "9"``.  Also the reference's top-2 logit gap per request.
+
 Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
 """
 from __future__ import annotations
@@ -63,6 +68,8 @@ class RefPredictor:
         self.ref.load_weights([(k, torch.from_numpy(v.astype(np.float32))) for k, v in ckpt.items()])
         self.calls = []          # request ids per obtain_aux_scores call
         self.seconds = 0.0
+        self.top2_gap = {}       # class mode: request -> (top-1 logit) - (top-2 logit) of the reference's own logits
+        self._rows_ids = None
 
     def _forward(self, rows):
         from vllm.attention.backends.torch_sdpa import TorchSDPAMetadata
@@ -80,21 +87,30 @@ class RefPredictor:
                               categorized_sample_indices=None, generators=None, perform_sampling=False)
         with torch.no_grad():
             hs, _ = self.ref(ids, pos, [None] * self.cfg.num_hidden_layers, md)
+            if self.cfg.num_labels > 1 and self._rows_ids is not None:
+                # the logits the reference's argmax sees (logits_processor.py:61-79: last-token rows x score.weight^T)
+                raw = self.ref.logits_processor(self.ref.score.weight, hs, sm)
+                top = torch.topk(raw.float(), 2, dim=-1).values
+                for rid, g in zip(self._rows_ids, (top[:, 0] - top[:, 1]).tolist()):
+                    self.top2_gap[rid] = g
             return self.ref.compute_logits(hs, sm)[:, 0].float().tolist()          # opt.py:399-409 .tolist()
 
     def obtain_aux_scores(self, sgs):                      # AUXLLM.obtain_aux_scores (aux_llm.py:125-126)
         t0 = time.time()
         self.calls.append([sg.request_id for sg in sgs])
-        pack, tok, out = [], 0, []
+        pack, pack_ids, tok, out = [], [], 0, []
         for sg in sgs:
             assert sg.need_aux_model_score()               # aux_llm_engine.py:409
             row = np.asarray(sg.prompt_token_ids, np.int64)
             if pack and tok + len(row) > 2048:
+                self._rows_ids = pack_ids
                 out += self._forward(pack)
-                pack, tok = [], 0
+                pack, pack_ids, tok = [], [], 0
             pack.append(row)
+            pack_ids.append(sg.request_id)
             tok += len(row)
         if pack:
+            self._rows_ids = pack_ids
             out += self._forward(pack)
         for sg, s in zip(sgs, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
@@ -251,9 +267,38 @@ def main_config3():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def main_tpt():
+    """Config 1's queue under `tpt`: class-mode predictor (82 labels), order (-score, request_id) on string ids."""
+    mg._init_dist()
+    torch.set_num_threads(os.cpu_count())
+    spec = OPTSpec.opt_125m(82)
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = synthetic_queue(spec, N_REQ, seed=0)
+    z1 = np.load(os.path.join(GOLD, "config1_opt125m_256.npz"), allow_pickle=False)
+    assert np.array_equal(z1["ids"], ids.astype(np.int32)) and np.array_equal(z1["cu_seqlens"], cu)   # the same queue
+    out = dict(seed=np.int64(0), num_labels=np.int64(82))
+    arrive_a = np.zeros(N_REQ, np.int32)
+    arrive_a[64:] = 1 + (np.arange(N_REQ - 64) // 8)
+    pred = RefPredictor(spec, ckpt)
+    s_a, sgs_a, rec_a = run("a", "tpt-xxx", pred, ids, cu, arrive_a, 36, 2048, 256, out)
+    scores = np.array([g.aux_model_score for g in sgs_a], np.float64)
+    assert (scores == np.rint(scores)).all() and scores.min() >= 0 and scores.max() <= 81
+    out["ref_score"] = scores.astype(np.float32)
+    out["ref_top2_gap"] = np.array([pred.top2_gap[str(i)] for i in range(N_REQ)], np.float32)
+    out["a_aux_calls"] = np.array([len(c) for c in pred.calls], np.int32)
+    labels, counts = np.unique(scores, return_counts=True)
+    print(f"tpt run a: {len(pred.calls)} predictor calls, {len(labels)} distinct labels over {N_REQ} requests (largest tie group "
+          f"{counts.max()}), smallest top-2 logit gap {out['ref_top2_gap'].min():.3e}; first order {rec_a['order'][0][:10].tolist()}")
+    path = os.path.join(GOLD, "config1_tpt_class82.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":
         return main_config3()
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "tpt":
+        return main_tpt()
     mg._init_dist()
     torch.set_num_threads(os.cpu_count())
     spec = OPTSpec.opt_125m()

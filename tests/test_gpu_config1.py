@@ -162,3 +162,32 @@ def test_config1_end_to_end_order_hip_scores_hip_sort(z, scorer, tag):
           f"{worst:.3e}; max|score error| {err:.3e}; closest pair of reference scores {np.diff(np.sort(ref)).min():.3e}")
     # (a near-tie is the same two requests step after step while both wait: config 3 has one pair 2.7e-6 apart)
     assert len(distinct) <= max(1, len(ref) // 100)
+
+
+def test_config1_tpt_class_head_end_to_end():
+    """Config 1's queue under `tpt` (tests/golden/config1_tpt_class82.npz: the reference's own Scheduler with its class-mode
+    predictor, 82 labels): the HIP class head (GEMM + first-maximum argmax) must give the reference's LABEL for every one
+    of the 256 requests (its closest top-2 logits are 2.5e-3 apart, 250x the score error), and then the order through
+    install() - (-score, request_id) on string ids, 219 requests in one tie group - is the reference's at every step, bit for
+    bit, end to end."""
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    z = np.load(os.path.join(GOLDEN, "config1_tpt_class82.npz"), allow_pickle=False)
+    q = np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
+    spec = OPTSpec.opt_125m(int(z["num_labels"]))
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", "f16")
+    labels = sc.score(q["ids"].astype(np.int64), q["cu_seqlens"])
+    assert np.array_equal(labels, z["ref_score"]), np.nonzero(labels != z["ref_score"])[0][:8]
+    groups = _groups(q)
+    ranker = MI355XRanker(sc, "tpt-xxx", max_length=2048, mtype="class")
+    zz = {k: z[k] for k in z.files}
+    zz.update(a_starv=np.int64(-1), a_period=np.int64(0))
+    s = ReplayScheduler(zz, "a", groups)
+    ranker.install(s)
+    for step in range(z["a_order"].shape[0]):
+        s.load_step(step)
+        s._schedule()
+        want = z["a_order"][step]
+        assert s.orders[-1] == want[want >= 0].tolist(), step
+    assert ranker.stats["aux_calls"] == len(z["a_aux_calls"])
+    assert [int(g.aux_model_score) for g in groups] == z["ref_score"].astype(int).tolist()

@@ -279,6 +279,30 @@ def test_config1_literal_sort_on_reference_scores_is_bit_identical(which):
         assert (promoted > 0) == (tag == "b")
 
 
+def test_config1_tpt_class_head_labels_and_string_tiebreak():
+    """Config 1's queue under `tpt`, run by the reference (oracle/make_config1_golden.py --config tpt): the class-mode
+    predictor (82 labels, float(argmax): opt.py:394-395) and the order (-score, request_id) on STRING request ids
+    (scheduler.py:938-948) - 15 distinct labels over 256 requests, the largest tie group 219.  The literal restatement on the
+    reference's labels must give the reference's order at every step (cheap, every step); the oracle's class head must give
+    the reference's labels (checked on the first 48 requests: the reference's closest top-2 logits are 2.5e-3 apart)."""
+    z = np.load(os.path.join(GOLDEN, "config1_tpt_class82.npz"), allow_pickle=False)
+    q = _config1()
+    ref = z["ref_score"]
+    assert float(z["ref_top2_gap"].min()) > 1e-3
+    reqs = {i: rs.Req(str(i), float(ref[i])) for i in range(len(ref))}
+    for step in range(z["a_order"].shape[0]):
+        concat = z["a_concat"][step]; concat = concat[concat >= 0]
+        want = z["a_order"][step]; want = want[want >= 0]
+        assert [int(r.request_id) for r in rs.tpt_order([reqs[int(i)] for i in concat])] == want.tolist(), step
+    assert z["a_order"][0][:4].tolist() == [0, 1, 10, 11]              # "10" < "2": string order inside the big tie group
+    spec = OPTSpec.opt_125m(int(z["num_labels"]))
+    orc = OracleOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])))
+    cu = q["cu_seqlens"]
+    k = 48
+    got = orc.score_packed(q["ids"][:cu[k]].astype(np.int64), cu[:k + 1])
+    assert np.array_equal(got, ref[:k])
+
+
 def test_install_surface_exists_on_the_reference_scheduler():
     """Every attribute MI355XRanker.install() / the wrapped _schedule touch was found on the reference's real Scheduler
     object (recorded by oracle/make_config1_golden.py run c, which also checked that the product wiring reproduces the
