@@ -23,6 +23,10 @@ project_in / project_out, 24 layers) on 128 requests of the LMSYS-like length pr
 "lmsys")``), runs ``a`` (starv 200 / period 10) and ``b`` (starv 6 / period 2, tight budget) as above - the second model
 family through the reference's own Scheduler + predictor.
 
+``--config xpt`` writes ``tests/golden/config1_xpt.npz``: config 1's queue and reference scores under ``xpt{table}`` (score ->
+expected length through a (key, value) table on ``round(-score, 2)``, order by ``expected_length - output_len``,
+scheduler.py:910-933), 60 steps, with the output lengths the key saw at every step.
+
 ``--config tpt`` writes ``tests/golden/config1_tpt_class82.npz``: config 1's queue (the ids live in ``config1_opt125m_256.npz``)
 scheduled by the reference under ``tpt`` - the class-mode predictor (``OPTSpec.opt_125m(82)``: ``compute_logits`` returns
 ``float(argmax)``, opt.py:394-395) and the order ``(-score, request_id)`` with STRING request ids (scheduler.py:938-948): 82
@@ -145,11 +149,14 @@ def run(tag, schedule_type, aux, ids, cu, arrive_at, steps, max_tokens, max_seqs
         captured["order"] = [int(g.request_id) for g in o]
         return o
     s._get_ordered_requests = spy
-    rec = {k: [] for k in ("concat", "order", "deques", "ran", "states", "need_tokens", "need_seqs", "chunkable", "granted")}
+    rec = {k: [] for k in ("concat", "order", "deques", "ran", "states", "need_tokens", "need_seqs", "chunkable", "granted", "out_len")}
     for step in range(steps):
         for i in np.nonzero(arrive_at == step)[0]:
             s.add_seq_group(sgs[i])
-        nd = np.zeros(n, np.int32); nq = np.zeros(n, np.int32); ck = np.zeros(n, np.uint8)
+        nd = np.zeros(n, np.int32); nq = np.zeros(n, np.int32); ck = np.zeros(n, np.uint8); ol = np.zeros(n, np.int32)
+        for dq in (s.waiting, s.running, s.swapped):
+            for g in dq:                                       # what the xpt key subtracts (scheduler.py:933)
+                ol[int(g.request_id)] = g.seqs_dict[next(iter(g.seqs_dict))].data.get_output_len()
         for dq, status in ((s.waiting, SequenceStatus.WAITING), (s.running, SequenceStatus.RUNNING),
                            (s.swapped, SequenceStatus.SWAPPED)):
             for g in dq:
@@ -175,7 +182,7 @@ def run(tag, schedule_type, aux, ids, cu, arrive_at, steps, max_tokens, max_seqs
             if hasattr(g, "pri"):
                 st[int(g.request_id)] = (g.pri, g.idle, g.runs)
         for k, v in (("concat", c), ("order", od), ("deques", np.asarray(captured["deques"], np.int32)), ("ran", ran),
-                     ("states", st), ("need_tokens", nd), ("need_seqs", nq), ("chunkable", ck), ("granted", gr)):
+                     ("states", st), ("need_tokens", nd), ("need_seqs", nq), ("chunkable", ck), ("granted", gr), ("out_len", ol)):
             rec[k].append(v)
     for k, v in rec.items():
         out[f"{tag}_{k}"] = np.stack(v)
@@ -294,7 +301,40 @@ def main_tpt():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def main_xpt():
+    """Config 1's queue and reference scores under `xpt{table}`: score -> expected length by table lookup on
+    round(-score, 2), order by expected_length - output_len (scheduler.py:910-933) - an order that moves every step."""
+    mg._init_dist()
+    z1 = np.load(os.path.join(GOLD, "config1_opt125m_256.npz"), allow_pickle=False)
+    ids, cu, ref = z1["ids"].astype(np.int64), z1["cu_seqlens"], z1["ref_score"]
+    lo, hi = float((-ref).min()), float((-ref).max())
+    key = np.round(np.linspace(lo - 0.02, hi + 0.02, 48), 2).tolist()                   # ascending thresholds on round(-score, 2)
+    value = (24 + 3 * np.arange(48) + np.random.RandomState(3).randint(0, 9, 48)).tolist()   # expected output lengths: several per step count
+    path_t = "/tmp/xpt_table_config1.pt"
+    torch.save((key, value), path_t)
+    table = {str(i): float(ref[i]) for i in range(N_REQ)}
+    out = dict(seed=np.int64(0), xpt_key=np.asarray(key, np.float64), xpt_value=np.asarray(value, np.int64))
+    arrive_a = np.zeros(N_REQ, np.int32)
+    arrive_a[64:] = 1 + (np.arange(N_REQ - 64) // 8)
+    s_a, sgs_a, rec_a = run("a", "xpt{" + path_t + "}-xxx", ScoreTable(table), ids, cu, arrive_a, 60, 2048, 256, out)
+    exp = np.array([g.expected_length for g in sgs_a], np.int64)
+    out["ref_expected_length"] = exp
+    # how far every score is from a rounding boundary of round(-score, 2): scores closer than the predictor's error could
+    # land in the neighbouring table row
+    x = -ref.astype(np.float64) * 100.0
+    out["ref_round_margin"] = (np.abs(x - np.floor(x) - 0.5) / 100.0).astype(np.float32)
+    orders = np.stack(rec_a["order"])
+    moved = sum(not np.array_equal(orders[i][orders[i] >= 0][:16], orders[i + 1][orders[i + 1] >= 0][:16]) for i in range(len(orders) - 1))
+    print(f"xpt run a: {len(set(exp.tolist()))} distinct expected lengths, head of the order changes in {moved} of {len(orders) - 1} "
+          f"steps, smallest rounding margin {out['ref_round_margin'].min():.3e}")
+    path = os.path.join(GOLD, "config1_xpt.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "xpt":
+        return main_xpt()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":
         return main_config3()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "tpt":

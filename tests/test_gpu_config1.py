@@ -191,3 +191,35 @@ def test_config1_tpt_class_head_end_to_end():
         assert s.orders[-1] == want[want >= 0].tolist(), step
     assert ranker.stats["aux_calls"] == len(z["a_aux_calls"])
     assert [int(g.aux_model_score) for g in groups] == z["ref_score"].astype(int).tolist()
+
+
+def test_config1_xpt_end_to_end():
+    """Config 1's queue under `xpt{table}` (tests/golden/config1_xpt.npz: the reference's own Scheduler, its table lookup on
+    round(-score, 2) and the SRTF key expected_length - output_len, scheduler.py:910-933, 60 steps): HIP scores -> the
+    plug-in's xpt order through install().  The lookup quantises the score to two decimals: every HIP score must fall in the
+    reference's table row (the closest reference score is 1.5e-5 from a rounding boundary, twice the score error), and then
+    the order is the reference's at every step, bit for bit."""
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    z = np.load(os.path.join(GOLDEN, "config1_xpt.npz"), allow_pickle=False)
+    q = np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
+    spec = OPTSpec.opt_125m()
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", "f16")
+    groups = _groups(q)
+    ranker = MI355XRanker(sc, "xpt{/nonexistent/table.pt}-xxx", max_length=2048,
+                          xpt_distribution=(z["xpt_key"].tolist(), z["xpt_value"].tolist()))
+    zz = {k: z[k] for k in z.files}
+    zz.update(a_starv=np.int64(-1), a_period=np.int64(0))
+    s = ReplayScheduler(zz, "a", groups)
+    ranker.install(s)
+    for step in range(z["a_order"].shape[0]):
+        s.load_step(step)
+        for g, n in zip(groups, z["a_out_len"][step]):
+            g.output_len = int(n)
+        s._schedule()
+        want = z["a_order"][step]
+        assert s.orders[-1] == want[want >= 0].tolist(), step
+    hip = np.array([g.aux_model_score for g in groups], np.float64)
+    err = float(np.abs(hip - q["ref_score"]).max())
+    assert err < float(z["ref_round_margin"].min()), (err, float(z["ref_round_margin"].min()))
+    assert [g.expected_length for g in groups] == z["ref_expected_length"].tolist()

@@ -303,6 +303,24 @@ def test_config1_tpt_class_head_labels_and_string_tiebreak():
     assert np.array_equal(got, ref[:k])
 
 
+def test_config1_xpt_literal_order_on_reference_scores():
+    """Config 1's queue under `xpt{table}`, run by the reference (oracle/make_config1_golden.py --config xpt): the literal
+    restatement of scheduler.py:910-933 on the reference's scores, its table and the output lengths of every step gives
+    the reference's order at all 60 steps (an SRTF order: it moves as requests generate tokens)."""
+    z = np.load(os.path.join(GOLDEN, "config1_xpt.npz"), allow_pickle=False)
+    ref = _config1()["ref_score"]
+    key, value = z["xpt_key"].tolist(), z["xpt_value"].tolist()
+    reqs = {i: rs.Req(str(i), float(ref[i])) for i in range(len(ref))}
+    for step in range(z["a_order"].shape[0]):
+        concat = z["a_concat"][step]; concat = concat[concat >= 0]
+        want = z["a_order"][step]; want = want[want >= 0]
+        ol = z["a_out_len"][step]
+        order = rs.xpt_order([reqs[int(i)] for i in concat], key, value, lambda q: int(ol[int(q.request_id)]))
+        assert [int(r.request_id) for r in order] == want.tolist(), step
+    assert [reqs[i].expected_length for i in range(len(ref))] == z["ref_expected_length"].tolist()
+    assert len({tuple(o[o >= 0][:16].tolist()) for o in z["a_order"]}) > 8          # the head of the order does move
+
+
 def test_install_surface_exists_on_the_reference_scheduler():
     """Every attribute MI355XRanker.install() / the wrapped _schedule touch was found on the reference's real Scheduler
     object (recorded by oracle/make_config1_golden.py run c, which also checked that the product wiring reproduces the
