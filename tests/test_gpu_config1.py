@@ -223,3 +223,25 @@ def test_config1_xpt_end_to_end():
     err = float(np.abs(hip - q["ref_score"]).max())
     assert err < float(z["ref_round_margin"].min()), (err, float(z["ref_round_margin"].min()))
     assert [g.expected_length for g in groups] == z["ref_expected_length"].tolist()
+
+
+@pytest.mark.parametrize("name,tag", [("config1_opt125m_256.npz", "a"), ("config1_opt125m_256.npz", "b"), ("config3_opt350m_128.npz", "a"),
+                                      ("config3_opt350m_128.npz", "b"), ("config1_tpt_class82.npz", "a"), ("config1_xpt.npz", "a")])
+def test_budget_walk_on_the_end_to_end_runs(name, tag):
+    """ltr_budget_prefix on every step of the reference's end-to-end runs (the order its scheduler saw, the per-request
+    needs): the selected prefix and the granted chunk sizes of the reference's schedule()."""
+    from vllm_ltr_amd.rank import budget_prefix
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    B, S = int(z[f"{tag}_token_budget"]), int(z[f"{tag}_max_num_seqs"])
+    for step in range(z[f"{tag}_order"].shape[0]):
+        o = z[f"{tag}_order"][step]
+        o = o[o >= 0].astype(np.int32)
+        if len(o) == 0:
+            continue
+        t = lambda k, dt: torch.from_numpy(z[f"{tag}_{k}"][step].astype(dt)).to(dev)
+        nsel, ran, granted = budget_prefix(torch.from_numpy(o).to(dev), t("need_tokens", np.int32), t("need_seqs", np.int32), B, S,
+                                           chunkable=t("chunkable", np.uint8))
+        n = int(nsel.item())
+        assert sorted(o[:n].tolist()) == np.nonzero(z[f"{tag}_ran"][step])[0].tolist(), step
+        assert granted.cpu().numpy()[o[:n]].tolist() == z[f"{tag}_granted"][step][o[:n]].tolist(), step

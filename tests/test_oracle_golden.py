@@ -321,6 +321,29 @@ def test_config1_xpt_literal_order_on_reference_scores():
     assert len({tuple(o[o >= 0][:16].tolist()) for o in z["a_order"]}) > 8          # the head of the order does move
 
 
+E2E_RUNS = [("config1_opt125m_256.npz", "a"), ("config1_opt125m_256.npz", "b"), ("config3_opt350m_128.npz", "a"),
+            ("config3_opt350m_128.npz", "b"), ("config1_tpt_class82.npz", "a"), ("config1_xpt.npz", "a")]
+
+
+@pytest.mark.parametrize("name,tag", E2E_RUNS)
+def test_budget_walk_on_the_end_to_end_runs(name, tag):
+    """The budget-walk restatement on every step of the reference's end-to-end runs: from the order the reference
+    scheduler saw and the per-request needs, the selected prefix and the granted chunk sizes of its schedule() (chunked
+    prefill; 2,048 / 256, 768 / 16 and 512 / 24 budgets)."""
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    B, S = int(z[f"{tag}_token_budget"]), int(z[f"{tag}_max_num_seqs"])
+    chunked = 0
+    for step in range(z[f"{tag}_order"].shape[0]):
+        o = z[f"{tag}_order"][step]
+        o = o[o >= 0]
+        nsel, granted = rs.budget_walk(z[f"{tag}_need_tokens"][step][o], z[f"{tag}_need_seqs"][step][o], B, S,
+                                       z[f"{tag}_chunkable"][step][o])
+        assert set(o[:nsel].tolist()) == set(np.nonzero(z[f"{tag}_ran"][step])[0].tolist()), step
+        assert granted == z[f"{tag}_granted"][step][o[:nsel]].tolist(), step
+        chunked += sum(g < n for g, n in zip(granted, z[f"{tag}_need_tokens"][step][o[:nsel]].tolist()))
+    assert chunked > 0
+
+
 def test_install_surface_exists_on_the_reference_scheduler():
     """Every attribute MI355XRanker.install() / the wrapped _schedule touch was found on the reference's real Scheduler
     object (recorded by oracle/make_config1_golden.py run c, which also checked that the product wiring reproduces the
