@@ -619,20 +619,23 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 // With M of a few hundred rows the 128 x 256 kernel has 3-12 workgroups, each walking its K-slabs behind a
 // two-stage ring at one DMA round trip per slab: 37 us per launch, 49 launches per scored request (2.1 ms for ONE
 // 86-token prompt, profiles/r02_ab_gemm_probes.txt section 5).  This variant spends the chip differently:
-//  * small tiles (BM x BN = 32 x 64 with 4 waves, or 64 x 128 with 8) so that a 1-request batch still makes 36-144
-//    workgroups and a 16-request batch fills every CU;
+//  * small tiles (BM x BN = 32 x 64 with 4 waves, 64 x 128 or 64 x 256 with 8) so that a 1-request batch still makes
+//    100-500 workgroups and a 16-request batch fills every CU;
 //  * 64-wide K stages in a RING OF FOUR (three stages in flight per workgroup, counted vmcnt, one raw barrier per
 //    stage) - latency-bound, so what matters is bytes in flight per CU, not bytes per FLOP;
+//  * an XCD grid of row ranges x column ranges chosen per launch, and K parts for the narrow long-K shape (launch_gemm);
 //  * the same fragment layout, the same MFMA (lo pass then hi pass per 32-wide slab, slabs in order) and the same
-//    epilogue arithmetic as the large-tile kernel: results are BIT-IDENTICAL to it, so a request's score does not
-//    depend on which kernel a batch size selects (tests/test_gpu_small_batches.py).
+//    epilogue arithmetic as the large-tile kernel.  Without K parts the results are bit-identical to it; with them the
+//    sums associate differently: a request's score moves by <= 2e-6 with the kernel a batch size selects, a call is
+//    deterministic (tests/test_gpu_small_batches.py).
 // ------------------------------------------------------------------------------------
 // Configuration of gemm_f16s_small_kernel: BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN)), SL 32-wide K-slabs
-// per ring stage, SSTAGES stages.  The shipped instances:
-//   32 x  64, 2 x 2 waves, 64-wide stages, ring of 4 (64 KiB)   - up to 1,024 rows (a handful of arrivals)
-//   64 x 128, 2 x 4 waves, 64-wide stages, ring of 4 (128 KiB)  - up to 3,072 rows
+// per ring stage, SSTAGES stages.  The shipped instances (which one runs: choose_small, from profiles/r04_small_gemm_lab.txt):
+//   32 x  64, 2 x 2 waves, 64-wide stages, ring of 4 (64 KiB)
+//   64 x 128, 2 x 4 waves, 64-wide stages, ring of 4 (128 KiB)
+//   64 x 256, 2 x 4 waves, 32-wide stages, ring of 4 (128 KiB)
 // (128 x 256, 2 x 4 waves, 32-wide stages, ring of 4 - the large-tile kernel's tile behind a deep ring at one workgroup
-//  per CU - also instantiates and is parity-green, but loses to its neighbours at every size: see launch_gemm)
+//  per CU - 32 x 128 and 64 x 64 also instantiate in the lab and are parity-green, but lose at every size)
 template <int BM_, int BN_, int WM_, int WN_, int SL_, int SSTAGES> struct SmallCfg {
   static constexpr int WM = WM_, WN = WN_;
   static constexpr int NW = WM * WN;
@@ -1166,12 +1169,11 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     static const int gm_wide = [] { const char* e = getenv("LTR_GEMM_GM"); return e ? atoi(e) : GM_DEFAULT; }();
     static const int gm_narrow = [] { const char* e = getenv("LTR_GEMM_GM_NARROW"); return e ? atoi(e) : (GM_DEFAULT | 65536); }();
     const int gm = tiles_n <= 4 ? gm_narrow : gm_wide;
-    // Small batches (a scheduler step with a few arrivals): the small-tile, deep-ring kernels (bit-identical results).
-    // LTR_GEMM_SMALL_M / LTR_GEMM_MID_M: row thresholds of the 32 x 64 / 64 x 128 tiles (0 switches a variant off; A/B
-    // knobs, profiles/r03_small_batch.txt).  A third configuration - the 128 x 256 tile behind a ring of four 32-wide
-    // stages at one workgroup per CU (SmallCfg<128, 256, 2, 4, 1, 4>, parity-green) - was measured for 1k-23k rows and
-    // is slower than both its neighbours everywhere (1,382 tokens: 2.21 vs 1.42 ms per call; 5,928: 3.31 vs 3.02;
-    // 23,078: 9.58 vs 8.61): not instantiated.
+    // Small batches (a scheduler step with a few arrivals): the small-tile, deep-ring kernels, chosen per launch by
+    // choose_small (LTR_GEMM_SMALL_M: the row count up to which they are considered at all; LTR_GEMM_FORCE_CFG /
+    // LTR_GEMM_FORCE_SPLIT: lab and tests).  (The 128 x 256 tile behind a ring of four 32-wide stages at one workgroup per
+    // CU - SmallCfg<128, 256, 2, 4, 1, 4>, parity-green - was measured for 1k-23k rows and is slower than its neighbours
+    // everywhere: 1,382 tokens 2.21 vs 1.42 ms per call, 5,928: 3.31 vs 3.02, 23,078: 9.58 vs 8.61 - not instantiated.)
     static const int map_mode = [] { const char* e = getenv("LTR_GEMM_SMALL_MAP"); return e ? atoi(e) : 3; }();
     static const int force_cfg = [] { const char* e = getenv("LTR_GEMM_FORCE_CFG"); return e ? atoi(e) : -2; }();       // diag: -1 big, 0, 1
     static const int force_split = [] { const char* e = getenv("LTR_GEMM_FORCE_SPLIT"); return e ? atoi(e) : 0; }();  // diag: parts (1 = off)
