@@ -66,8 +66,10 @@ class HipPredictorTrainer:
             raise _lib.LtrError("HipPredictorTrainer needs a ROCm GPU (no CPU fallback on the product path)")
         if loss == "neuralNDCG":
             raise NotImplementedError("loss 'neuralNDCG' (trainer.py:127-128, allrank/models/losses/neuralNDCG.py) is not built: "
-                                      "every recipe in train/train.sh uses listMLE or the class heads; use listMLE, mse or "
-                                      "crossentropy")
+                                      "every recipe in train/train.sh uses listMLE or the class heads, and on the trainer's own "
+                                      "labels (label_max_length - length: up to 8192) the reference's neuralNDCG is NaN - its "
+                                      "2^label gain overflows f32 from label 128 on (checked against the reference's code); "
+                                      "use listMLE, mse or crossentropy")
         if loss not in _lib.LOSSES:
             raise ValueError(f"loss {loss!r}: one of {sorted(_lib.LOSSES)} (trainer.py:125-132)")
         self.lib = _lib.load()
