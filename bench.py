@@ -212,7 +212,7 @@ def run_trace(args, spec, ckpt, dev):
     from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
     from vllm_ltr_amd.scorer import HipOPTScorer
     scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype)
-    ranker = MI355XRanker(scorer, f"opt-xxx-starv{args.starv}-period{args.period}", max_length=1024)
+    ranker = MI355XRanker(scorer, f"opt-xxx-starv{args.starv}-period{args.period}", max_length=1024, prescore=args.prescore)
     reqs = synthetic_trace(spec.vocab_size, args.trace_requests, args.trace, args.trace_rate, args.trace_cv, seed=0,
                            prompt_median=PROFILES[args.profile])
     # warm the kernels / allocator on a throw-away ranker-sized call
@@ -227,8 +227,9 @@ def run_trace(args, spec, ckpt, dev):
            "config": {"workload": f"OPT-{args.model} predictor, {args.trace} trace of {args.trace_requests} requests"
                                   + (f" at {args.trace_rate} req/s, cv {args.trace_cv}" if args.trace == "gamma" else " at t = 0")
                                   + f", stand-in backbone step {args.trace_backbone_ms} ms, budget 2048 tokens / 256 seqs",
-                      "starv": args.starv, "period": args.period},
-           "trace": s}
+                      "starv": args.starv, "period": args.period,
+                      "prescore": bool(args.prescore)},
+           "trace": s, "ranker_metrics": ranker.metrics()}
     print(json.dumps(out))
 
 
@@ -307,6 +308,7 @@ def main():
     ap.add_argument("--train-slate", type=int, default=32)
     ap.add_argument("--train-precision", default="both", choices=["both", "split"],
                     help="both: also time the exact-f32 path for comparison; split: the product path only (profiling)")
+    ap.add_argument("--prescore", action="store_true", help="trace replay: score requests when they arrive (MI355XRanker(prescore=True))")
     ap.add_argument("--trace-requests", type=int, default=2000)
     ap.add_argument("--trace-rate", type=float, default=16.0)
     ap.add_argument("--trace-cv", type=float, default=1.0)

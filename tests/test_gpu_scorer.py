@@ -744,14 +744,17 @@ def test_layernorm_fold_on_and_off_agree(dev, monkeypatch, variant):
 
 
 # tiny_*: the OPT-125m and the OPT-350m block structures; opt350m: config 5's predictor itself at its true shape (2,000 requests)
-@pytest.mark.parametrize("family", ["tiny_pre_ln", "tiny_post_ln", "opt350m"])
+@pytest.mark.parametrize("family,prescore", [("tiny_pre_ln", False), ("tiny_post_ln", False), ("opt350m", False),
+                                             ("tiny_pre_ln", True), ("opt350m", True)])
 @pytest.mark.parametrize("kind", ["burst", "gamma"])
-def test_config5_ranker_side_trace_replay(dev, kind, family):
+def test_config5_ranker_side_trace_replay(dev, kind, family, prescore):
     """BASELINE config 5, the ranker's share: a burst (everything at t = 0, benchmarks/burst-*.sh) and a gamma arrival
     process (benchmark_serving_real.py:159-176) replayed through MI355XRanker.install() on an (unpatched) scheduler
     loop - per step k arrivals -> obtain_aux_scores(k) + order + aging.  EVERY step's order is compared with the
     literal reference expressions (promote/demote + stable sorted, scheduler.py:984-998; aging :1358-1365) replayed
-    on the same deques; every request finishes; latency percentiles come out of the summary."""
+    on the same deques; every request finishes; latency percentiles come out of the summary.  ``prescore``: the same with
+    the requests scored when they ARRIVE (asynchronously, ``MI355XRanker(prescore=True)``): same checks, and the scheduler
+    steps that admit arrivals no longer wait for a forward."""
     from oracle import rank_step as rs
     from vllm_ltr_amd.plugin import MI355XRanker
     from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
@@ -761,12 +764,12 @@ def test_config5_ranker_side_trace_replay(dev, kind, family):
     sc = _scorer(spec, ckpt, dev, "f16")
     n_req = 2000 if true_shape else 400
     if true_shape:       # bench.py --trace --model 350m: 2,048-token / 256-sequence budget, prompts of median 64
-        ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=1024)
+        ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=1024, prescore=prescore)
         reqs = synthetic_trace(spec.vocab_size, n_req, kind, request_rate=64.0, cv=1.0, seed=0, prompt_median=64.0,
                                output_median=24.0)
         budget = dict(backbone_ms=25.0, max_num_batched_tokens=2048, max_num_seqs=256)
     else:
-        ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=150)
+        ranker = MI355XRanker(sc, "opt-xxx-starv20-period3", max_length=150, prescore=prescore)
         reqs = synthetic_trace(spec.vocab_size, n_req, kind, request_rate=200.0, cv=2.0, seed=1, prompt_median=24.0,
                                output_median=12.0, max_prompt=140)
         budget = dict(backbone_ms=5.0, max_num_batched_tokens=256, max_num_seqs=16)
@@ -788,8 +791,15 @@ def test_config5_ranker_side_trace_replay(dev, kind, family):
 
     res = replay(ranker, reqs, before_step=before, on_step=after, **budget)
     s = summarize(res)
-    print(f"{family} {kind}: {s['steps']} steps, max queue {s['max_queue']}, ranker p50/p95/p99 = {s['ranker_ms_all']['p50']:.3f} / "
-          f"{s['ranker_ms_all']['p95']:.3f} / {s['ranker_ms_all']['p99']:.3f} ms, ranker share of HOL {s['ranker_share_of_hol']:.3f}")
+    print(f"{family} {kind}{' prescore' if prescore else ''}: {s['steps']} steps, max queue {s['max_queue']}, ranker p50/p95/p99 = "
+          f"{s['ranker_ms_all']['p50']:.3f} / {s['ranker_ms_all']['p95']:.3f} / {s['ranker_ms_all']['p99']:.3f} ms, steps with arrivals p50 "
+          f"{s['ranker_ms_with_arrivals']['p50']:.3f} ms, ranker share of HOL {s['ranker_share_of_hol']:.3f}")
+    if prescore:
+        m = ranker.metrics()["prescore"]
+        print("prescore:", m)
+        assert m["requests"] + 0 <= n_req and m["requests"] >= (n_req // 2 if kind == "gamma" else 1)
+        if kind == "burst":
+            assert m["launches"] <= 16                         # a burst of 400 / 2,000 arrivals: ~log2 N growing batches, not one launch each
     assert s["finished"] == n_req and all(r.aux_model_score is not None for r in reqs)
     assert ranker.stats["requests_scored"] == n_req            # every request scored exactly once
     if true_shape:       # the scores the replay ran on, against the oracle (first / last arrivals and a few in between)
@@ -802,7 +812,7 @@ def test_config5_ranker_side_trace_replay(dev, kind, family):
     if not (true_shape and kind == "gamma"):                   # (64 req/s against a 256-sequence budget never starves a request)
         assert state["promoted"] > 0                           # starvation promotions happened and matched
     if kind == "burst":
-        assert s["ranker_ms_with_arrivals"]["n"] == 1          # one cold call for the whole burst
+        assert s["ranker_ms_with_arrivals"]["n"] == 1          # one scoring step for the whole burst
     else:
         assert s["ranker_ms_with_arrivals"]["n"] > 20
     assert s["ranker_ms_steady"]["p50"] < 5.0

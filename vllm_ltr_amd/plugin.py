@@ -99,11 +99,14 @@ class _PinnedI32:
 
 
 class MI355XRanker:
+    PRESCORE_WINDOW_S = 3e-4     # prescore: arrivals closer together than the host time of one launch share a forward
+    PRESCORE_BURST_S = 5e-3      # prescore: launches inside this window count as one burst (growing batches)
+
     def __init__(self, scorer: HipOPTScorer, schedule_type: str = "opt", max_length: int = 2048,
                  tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank",
                  xpt_distribution=None, group=None, min_requests_to_shard: Optional[int] = None,
                  min_tokens_to_shard: Optional[int] = None, collective_timeout_s: Optional[float] = None,
-                 mirror_host: bool = False):
+                 mirror_host: bool = False, prescore: bool = False):
         """
         scorer      the HBM-resident predictor
         schedule_type  the reference's schedule string (``opt-...-starv<S>-period<P>``; an ``xpt{path}...``
@@ -125,6 +128,13 @@ class MI355XRanker:
                     sharded call: a dead peer raises :class:`~vllm_ltr_amd.distributed.PeerTimeout` on the surviving ranks.
         mirror_host write ``pri/idle/runs`` back to the request objects every step (what the reference's loops
                     do; costs a D2H copy + a Python loop per step).  Default: device-resident only.
+        prescore    score a request when it ARRIVES (``add_request``, where ``Scheduler.add_seq_group`` runs) instead of
+                    inside the scheduler step: the forward is launched asynchronously on a second stream while the engine
+                    is busy with the backbone step, and ``obtain_aux_scores`` - which blocks the engine loop
+                    (SURVEY.md 8b "Threading") - only collects what is already there.  Arrivals that come while a
+                    forward is in flight are batched into the next one.  Same kernels, same scores (up to the batch a
+                    request is scored in: the <= 2e-6 of DESIGN.md 4.1b); not with ``group=`` (every rank must make the
+                    same collective calls).  Off by default: the reference scores at the step.
         """
         self.scorer = scorer
         self.device = scorer.device
@@ -167,6 +177,18 @@ class MI355XRanker:
         # wall time of the last 1,000 scoring / ordering calls ("calls, requests scored, ms/call")
         self._score_ms: collections.deque = collections.deque(maxlen=1000)
         self._rank_ms: collections.deque = collections.deque(maxlen=1000)
+        # ---- asynchronous scoring at arrival (prescore=True)
+        if prescore and group is not None:
+            raise ValueError("prescore=True does not combine with group=: the ranks of a sharded call must make the same "
+                             "collective calls, and arrivals are not synchronised across ranks")
+        self.prescore = bool(prescore)
+        self._pre_stream = torch.cuda.Stream(self.device) if self.prescore else None
+        self._pre_pending: list = []                     # arrivals not yet launched
+        self._pre_inflight: collections.deque = collections.deque()    # launched batches, oldest first
+        self._pre_free_stagers: list = []
+        self._pre_up = _PinnedI32(self.device, 1 << 8) if self.prescore else None
+        self._pre_recent: collections.deque = collections.deque()     # issue times of the launches of the last PRESCORE_BURST_S
+        self.stats.update(prescore_launches=0, prescored_requests=0, prescore_wait_seconds=0.0, arrival_hook_seconds=0.0)
 
     # ---- construction from the reference's config objects ------------------------------
     @classmethod
@@ -241,8 +263,64 @@ class MI355XRanker:
     # ---- AUXLLM.obtain_aux_scores -------------------------------------------------------
     def add_request(self, sg) -> None:
         """Optional arrival-time hook (where ``Scheduler.add_seq_group`` runs, scheduler.py:368-376):
-        tokenise / truncate the prompt once so the scoring call only packs cached arrays."""
+        tokenise / truncate the prompt once so the scoring call only packs cached arrays.  With ``prescore=True`` the
+        request's forward is also started here, asynchronously (see the constructor)."""
         cached_token_ids(sg, self.tokenize, self.max_length)
+        if self.prescore and sg.need_aux_model_score() and getattr(sg, "_ltr_pre", None) is None:
+            t0 = time.perf_counter()
+            self._pre_pending.append(sg)
+            self._prescore_pump()
+            self.stats["arrival_hook_seconds"] += time.perf_counter() - t0
+
+    def _prescore_pump(self, force: bool = False) -> None:
+        """Launch a forward over the pending arrivals - a lone arrival always starts at once - unless
+        * the previous launch was issued less than ``PRESCORE_WINDOW_S`` ago (arrivals closer together than the host time of
+          a launch share a forward), or
+        * this is a burst: from the third launch inside ``PRESCORE_BURST_S`` on, a launch needs twice as many pending
+          arrivals as the one before (2, 4, 8, ...: a burst of N arrivals costs ~log2 N launches however slow the host
+          is, instead of one-request forwards issued back to back), or
+        * two launched batches are still unfinished (one running, one queued behind it).
+        What is held back goes with the next pump - every ``add_request``; the end of every scheduler step (``age``), which
+        forces it - or is scored by ``obtain_aux_scores`` itself when the step asks for it first."""
+        if not self._pre_pending:
+            return
+        now = time.perf_counter()
+        recent = self._pre_recent
+        while recent and now - recent[0] > self.PRESCORE_BURST_S:
+            recent.popleft()
+        if not force:
+            if recent and now - recent[-1] < self.PRESCORE_WINDOW_S:
+                return
+            if len(recent) >= 2 and len(self._pre_pending) < min(1 << (len(recent) - 1), 4096):
+                return
+            if len(self._pre_inflight) >= 2 and not self._pre_inflight[-1]["event"].query() \
+                    and not self._pre_inflight[-2]["event"].query():
+                return
+        recent.append(now)
+        batch, self._pre_pending = self._pre_pending, []
+        arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in batch]
+        stager = self._pre_free_stagers.pop() if self._pre_free_stagers else InputStager(self.device, 1 << 12, 1 << 6)
+        with torch.cuda.stream(self._pre_stream):
+            ids_dev, cu_dev, cu_host = stager.stage(arrays)
+            scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host, workspace_key="prescore")
+            scores_host = stager._sc_h[:len(batch)]
+            scores_host.copy_(scores_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._pre_stream)
+        rec = dict(reqs=batch, scores_dev=scores_dev, scores_host=scores_host, event=ev, stager=stager, left=len(batch))
+        for i, sg in enumerate(batch):
+            sg._ltr_pre = (rec, i)
+        self._pre_inflight.append(rec)
+        self.stats["prescore_launches"] += 1
+        # batches nobody collected (aborted requests): keep the list bounded
+        while len(self._pre_inflight) > 256 and self._pre_inflight[0]["event"].query():
+            self._prescore_retire(self._pre_inflight.popleft())
+
+    def _prescore_retire(self, rec) -> None:
+        for sg in rec["reqs"]:
+            if getattr(sg, "_ltr_pre", None) is not None and sg._ltr_pre[0] is rec:
+                sg._ltr_pre = None
+        self._pre_free_stagers.append(rec["stager"])
 
     def obtain_aux_scores(self, seq_groups) -> List[float]:
         seq_groups = list(seq_groups)
@@ -251,20 +329,27 @@ class MI355XRanker:
         t0 = time.perf_counter()
         for sg in seq_groups:
             assert sg.need_aux_model_score()               # aux_llm_engine.py:409
-        arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in seq_groups]
-        ids_dev, cu_dev, cu_host = self._stager.stage(arrays)          # pinned pack + async H2D
-        if self._sharded is not None:
-            scores_dev = self._sharded.score_device(ids_dev, cu_dev, cu_host)
-        else:
-            scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host)
-        # the scores stay on the device in the requests' slots; the host copy is only for the
-        # reference-visible ``aux_model_score`` attribute
-        self._assign_slots(seq_groups, being_scored=True)
-        slots = torch.from_numpy(np.fromiter(map(self._get_slot, seq_groups), np.int64, len(seq_groups))).to(self.device)
-        self.queue.set_scores(slots, scores_dev)
-        scores = self._stager.fetch_scores(scores_dev)
+        out: List[Optional[float]] = [None] * len(seq_groups)
+        todo = list(range(len(seq_groups)))
+        if self.prescore:
+            todo = self._collect_prescored(seq_groups, out)
+        if todo:
+            batch = [seq_groups[i] for i in todo]
+            arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in batch]
+            ids_dev, cu_dev, cu_host = self._stager.stage(arrays)          # pinned pack + async H2D
+            if self._sharded is not None:
+                scores_dev = self._sharded.score_device(ids_dev, cu_dev, cu_host)
+            else:
+                scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host)
+            # the scores stay on the device in the requests' slots; the host copy is only for the
+            # reference-visible ``aux_model_score`` attribute
+            self._assign_slots(batch, being_scored=True)
+            slots = torch.from_numpy(np.fromiter(map(self._get_slot, batch), np.int64, len(batch))).to(self.device)
+            self.queue.set_scores(slots, scores_dev)
+            scores = self._stager.fetch_scores(scores_dev)
+            for i, v in zip(todo, scores.tolist()):            # opt.py:408 .tolist()
+                out[i] = v
         self._check_status()                               # out-of-vocabulary ids raise, like F.embedding
-        out = scores.tolist()                              # opt.py:408 .tolist()
         for sg, s in zip(seq_groups, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
         dt = time.perf_counter() - t0
@@ -273,6 +358,50 @@ class MI355XRanker:
         self.stats["score_seconds"] += dt
         self._score_ms.append(dt * 1e3)
         return out
+
+    def _collect_prescored(self, seq_groups, out) -> list:
+        """Scores of the requests whose forward was started at arrival: into their device slots (the ordering reads them
+        there) and into ``out``.  Returns the positions that still need a forward (arrivals never handed to
+        ``add_request``, or still waiting for a launch)."""
+        pending = {id(sg) for sg in self._pre_pending}
+        if pending:                                        # not launched yet: they go into this step's own batch
+            ask = {id(sg) for sg in seq_groups}
+            self._pre_pending = [sg for sg in self._pre_pending if id(sg) not in ask]
+        todo, by_rec = [], {}
+        for i, sg in enumerate(seq_groups):
+            pre = getattr(sg, "_ltr_pre", None)
+            if pre is None:
+                todo.append(i)
+            else:
+                by_rec.setdefault(id(pre[0]), (pre[0], []))[1].append((i, pre[1], sg))
+        n_pre = sum(len(items) for _, items in by_rec.values())
+        if n_pre:
+            # one pinned upload for all of them: [slots | score bits] as int32 (the host values are the D2H copies the
+            # forwards left behind; the slots then hold exactly what the request objects get)
+            self._pre_up.ensure(2 * n_pre)
+            buf = self._pre_up.np
+            buf_f = buf.view(np.float32)
+            k = 0
+            for rec, items in by_rec.values():
+                t0 = time.perf_counter()
+                rec["event"].synchronize()                 # normally long done: the forward ran during the backbone step
+                self.stats["prescore_wait_seconds"] += time.perf_counter() - t0
+                self._assign_slots([sg for _, _, sg in items], being_scored=True)
+                host = rec["scores_host"].numpy()
+                for i, j, sg in items:
+                    buf[k] = self._get_slot(sg)
+                    buf_f[n_pre + k] = host[j]
+                    out[i] = float(host[j])
+                    sg._ltr_pre = None
+                    k += 1
+                rec["left"] -= len(items)
+            up = self._pre_up.upload(2 * n_pre)
+            self.queue.set_scores(up[:n_pre].to(torch.int64), up[n_pre:].view(torch.float32))
+            self.stats["prescored_requests"] += n_pre
+        # retire finished batches from the head of the list (their staging buffers go back to the pool)
+        while self._pre_inflight and self._pre_inflight[0]["left"] <= 0:
+            self._prescore_retire(self._pre_inflight.popleft())
+        return todo
 
     def metrics(self) -> dict:
         """Counters of the ranking path: calls, requests scored, mean ms per call since construction and
@@ -291,7 +420,10 @@ class MI355XRanker:
                               last=pct(self._rank_ms)),
                     live_slots=self._live_slots, queue_length=self._n_members,
                     sharded=self._sharded is not None,
-                    two_lane_calls=self.scorer.lane_calls() if hasattr(self.scorer, "lane_calls") else 0)
+                    two_lane_calls=self.scorer.lane_calls() if hasattr(self.scorer, "lane_calls") else 0,
+                    prescore=dict(enabled=self.prescore, launches=st["prescore_launches"], requests=st["prescored_requests"],
+                                  wait_ms_total=st["prescore_wait_seconds"] * 1e3,
+                                  arrival_hook_ms_total=st["arrival_hook_seconds"] * 1e3))
 
     def _check_status(self) -> None:
         """Raise where the reference's F.embedding raises (a token id outside the vocabulary), or when the residual
@@ -448,6 +580,8 @@ class MI355XRanker:
         q.age(members=self._members_dev, ran_slots=self._ran.upload(k))
         if self.mirror_host:
             self.sync_host(all_pri)
+        if self.prescore:
+            self._prescore_pump(force=True)                # whatever was held back: the next step is a backbone step away
 
     def sync_host(self, reqs: Sequence) -> None:
         """Refresh ``pri / idle / runs`` of the request objects from their device slots."""

@@ -16,7 +16,17 @@ decode token per scheduled request per step), and records the ranker's wall time
 Virtual clock: ``t += ranker wall time of the step + backbone_ms``; a request joins ``waiting`` in the
 first step whose start time is >= its arrival time.  ``ranker_delay`` of a request = the ranker wall
 time accumulated over the steps between its arrival and its first scheduling = the ranker-induced part
-of its head-of-line time ``HOL = first_scheduled - arrival``.
+of its head-of-line time ``HOL = first_scheduled - arrival``.  The ranker's time of a step = its
+``_schedule()`` - what blocks the engine loop; the arrival hooks (``add_request``) are timed separately
+(``arrival_hook_ms``): in the reference's serving path they run on the event-loop thread while the backbone step
+runs in the executor thread (async_llm_engine.py: ``step_async`` -> ``execute_model_async``), i.e. beside the step.
+``ranker_ms_*_incl_hooks`` adds them to the step for the synchronous engine (entrypoints/llm.py), where they are not.
+
+Scoring at arrival (``MI355XRanker(prescore=True)``): a request that arrives at virtual time ``a`` during the
+backbone step is handed to ``add_request`` there and the scheduler step starts at ``t >= a``; the forward has
+``t - a`` of the engine's time to finish.  The replay gives it that lead in REAL time, capped at ``lead_cap_ms``
+per step (6 ms of a 25-ms backbone step: a few one-request forwards; a longer lead changes nothing, a shorter one is
+honoured exactly - the replay never grants more overlap than the trace has).
 """
 from __future__ import annotations
 
@@ -118,7 +128,7 @@ class ReplayScheduler:
 
 def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max_num_batched_tokens: int = 2048,
            max_num_seqs: int = 256, max_steps: int = 1 << 20, on_step: Optional[Callable] = None,
-           before_step: Optional[Callable] = None) -> Dict:
+           before_step: Optional[Callable] = None, lead_cap_ms: float = 6.0) -> Dict:
     """Run the trace to completion.  Returns per-step ranker wall times (ms), the number of arrivals scored per step,
     the queue length per step and per-request HOL / ranker_delay (s).  ``on_step(step, scheduler, ran)`` is called
     after every step, ``before_step(step, scheduler)`` right before its ``_schedule()`` with the arrivals already in
@@ -127,8 +137,9 @@ def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max
     ranker.install(sched)
     pending = deque(sorted(requests, key=lambda r: r.arrival))
     t = 0.0
-    step_ms, step_new, step_queue = [], [], []
+    step_ms, step_new, step_queue, step_hook_ms = [], [], [], []
     finished = 0
+    prescore = bool(getattr(ranker, "prescore", False))
     n = len(requests)
     dev = ranker.device
     for step in range(max_steps):
@@ -137,21 +148,35 @@ def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max
         if not (sched.waiting or sched.running or sched.swapped) and pending and pending[0].arrival > t:
             t = pending[0].arrival                           # idle engine: jump to the next arrival
         k = 0
+        hook = 0.0
+        lead_left = lead_cap_ms * 1e-3
         while pending and pending[0].arrival <= t:
             r = pending.popleft()
-            ranker.add_request(r)                            # arrival-time hook (tokenise / truncate once)
+            h0 = time.perf_counter()
+            ranker.add_request(r)                            # arrival-time hook (tokenise / truncate once; prescore: launch)
+            hook += time.perf_counter() - h0
             sched.waiting.append(r)
             k += 1
+            if prescore and lead_left > 0:
+                # the engine time between this arrival and the next one / the start of the step, in real time (capped)
+                nxt = pending[0].arrival if pending and pending[0].arrival <= t else t
+                lead = min(max(nxt - r.arrival, 0.0), lead_left)
+                if lead > 0:
+                    end = time.perf_counter() + lead
+                    while time.perf_counter() < end:         # (sleep() overshoots by tens of microseconds)
+                        pass
+                    lead_left -= lead
         qlen = len(sched.waiting) + len(sched.running) + len(sched.swapped)
         unscheduled = [g for g in sched.waiting if g.first_scheduled is None]
         if before_step is not None:
             before_step(step, sched)
-        torch.cuda.synchronize(dev)
+        if not prescore:
+            torch.cuda.synchronize(dev)                      # (prescore: the forward of the arrivals may still be running - that is the point)
         t0 = time.perf_counter()
         ret = sched._schedule()                              # obtain_aux_scores(k) + order + budget walk + aging
-        torch.cuda.synchronize(dev)
+        torch.cuda.current_stream(dev).synchronize()
         dt = time.perf_counter() - t0
-        step_ms.append(dt * 1e3); step_new.append(k); step_queue.append(qlen)
+        step_ms.append(dt * 1e3); step_new.append(k); step_queue.append(qlen); step_hook_ms.append(hook * 1e3)
         ran = [x.seq_group for x in ret.scheduled_seq_groups]
         t_sched = t + dt
         for g in unscheduled:                                # the step's ranker time precedes any scheduling it decides
@@ -175,6 +200,7 @@ def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max
     hol = np.array([r.first_scheduled - r.arrival for r in requests if r.first_scheduled is not None])
     delay = np.array([r.ranker_delay for r in requests if r.first_scheduled is not None])
     return dict(step_ms=np.asarray(step_ms), step_new=np.asarray(step_new), step_queue=np.asarray(step_queue),
+                step_hook_ms=np.asarray(step_hook_ms),
                 hol_s=hol, ranker_delay_s=delay, finished=finished, virtual_seconds=t)
 
 
@@ -190,6 +216,11 @@ def summarize(res: Dict) -> Dict:
         a = ms[sel]
         out[f"ranker_ms_{name}"] = dict(n=int(sel.sum()), p50=pct(a, 50), p95=pct(a, 95), p99=pct(a, 99),
                                         max=float(a.max()) if len(a) else None)
+    if "step_hook_ms" in res:
+        hk = res["step_hook_ms"]
+        out["arrival_hook_ms_per_scoring_step"] = dict(p50=pct(hk[new > 0], 50), p99=pct(hk[new > 0], 99))
+        a = (ms + hk)[new > 0]
+        out["ranker_ms_with_arrivals_incl_hooks"] = dict(n=int((new > 0).sum()), p50=pct(a, 50), p95=pct(a, 95), p99=pct(a, 99))
     d, h = res["ranker_delay_s"], res["hol_s"]
     out["ranker_hol_delay_ms"] = dict(p50=pct(d * 1e3, 50), p95=pct(d * 1e3, 95), p99=pct(d * 1e3, 99))
     out["hol_ms"] = dict(p50=pct(h * 1e3, 50), p95=pct(h * 1e3, 95), p99=pct(h * 1e3, 99))

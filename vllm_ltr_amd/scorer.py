@@ -87,6 +87,7 @@ class HipOPTScorer:
         if chunk_tokens:
             self.set_chunk_tokens(chunk_tokens)
         self._ws: Optional[torch.Tensor] = None
+        self._ws_by_key: dict = {}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -118,8 +119,16 @@ class HipOPTScorer:
                 for i, k in enumerate(_lib.PROFILE_KINDS)}
 
     # ------------------------------------------------------------------ helpers
-    def _workspace(self, N: int, T: int) -> torch.Tensor:
+    def _workspace(self, N: int, T: int, key: Optional[str] = None) -> torch.Tensor:
+        """The scoring workspace (grown on demand).  ``key``: a second, independent workspace for calls that run on ANOTHER
+        stream at the same time as the default one's (the handle allows concurrent calls; they must not share scratch)."""
         need = int(self.lib.ltr_workspace_bytes(self._h, _lib.LTR_WS_SCORE, N, T))
+        if key is not None:
+            ws = self._ws_by_key.get(key)
+            if ws is None or ws.numel() < need:
+                self._ws_by_key[key] = None
+                ws = self._ws_by_key[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            return ws
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -148,9 +157,10 @@ class HipOPTScorer:
     # ------------------------------------------------------------------ calls
     def score_device(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray,
                      logits_out: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, workspace_key: Optional[str] = None) -> torch.Tensor:
         """Inputs already resident in HBM (int64 [T], int32 [N+1]); returns f32 [N] on
-        the device.  ``cu_host`` is the host mirror of ``cu_dev``.  Asynchronous."""
+        the device.  ``cu_host`` is the host mirror of ``cu_dev``.  Asynchronous, on torch's current stream;
+        ``workspace_key``: see :meth:`_workspace` (calls in flight on two streams)."""
         N = int(cu_host.shape[0]) - 1
         T = int(cu_host[-1]) if N >= 0 else 0
         if out is None:
@@ -159,7 +169,7 @@ class HipOPTScorer:
             return out
         assert ids_dev.dtype == torch.int64 and cu_dev.dtype == torch.int32
         cu_host = np.ascontiguousarray(cu_host, dtype=np.int32)
-        ws = self._workspace(N, T)
+        ws = self._workspace(N, T, workspace_key)
         max_len = int(np.diff(cu_host).max())
         # (the library makes the handle's device current itself; the torch context keeps the workspace
         # allocation and the stream lookup on the same device)
