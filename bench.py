@@ -212,12 +212,14 @@ def run_trace(args, spec, ckpt, dev):
     from vllm_ltr_amd.replay import replay, summarize, synthetic_trace
     from vllm_ltr_amd.scorer import HipOPTScorer
     scorer = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype)
-    ranker = MI355XRanker(scorer, f"opt-xxx-starv{args.starv}-period{args.period}", max_length=1024, prescore=args.prescore)
+    ranker = MI355XRanker(scorer, f"opt-xxx-starv{args.starv}-period{args.period}", max_length=1024, prescore=args.prescore,
+                          prescore_graphs=not args.no_prescore_graphs)
     reqs = synthetic_trace(spec.vocab_size, args.trace_requests, args.trace, args.trace_rate, args.trace_cv, seed=0,
                            prompt_median=PROFILES[args.profile])
     # warm the kernels / allocator on a throw-away ranker-sized call
     warm = synthetic_trace(spec.vocab_size, 64, "burst", seed=7)
     ranker.obtain_aux_scores(warm)
+    ranker.warm_prescore_graphs()
     res = replay(ranker, reqs, backbone_ms=args.trace_backbone_ms)
     s = summarize(res)
     out = {"metric": "ranker latency per scheduler step under an arrival trace (obtain_aux_scores + order + budget walk + aging "
@@ -309,6 +311,7 @@ def main():
     ap.add_argument("--train-precision", default="both", choices=["both", "split"],
                     help="both: also time the exact-f32 path for comparison; split: the product path only (profiling)")
     ap.add_argument("--prescore", action="store_true", help="trace replay: score requests when they arrive (MI355XRanker(prescore=True))")
+    ap.add_argument("--no-prescore-graphs", action="store_true", help="with --prescore: launch every forward eagerly (no captured graphs)")
     ap.add_argument("--trace-requests", type=int, default=2000)
     ap.add_argument("--trace-rate", type=float, default=16.0)
     ap.add_argument("--trace-cv", type=float, default=1.0)

@@ -101,12 +101,13 @@ class _PinnedI32:
 class MI355XRanker:
     PRESCORE_WINDOW_S = 3e-4     # prescore: arrivals closer together than the host time of one launch share a forward
     PRESCORE_BURST_S = 5e-3      # prescore: launches inside this window count as one burst (growing batches)
+    PRESCORE_GRAPH_BUCKET = 64   # prescore: one captured graph per this many tokens of (prompt + >= 1 dummy token)
 
     def __init__(self, scorer: HipOPTScorer, schedule_type: str = "opt", max_length: int = 2048,
                  tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank",
                  xpt_distribution=None, group=None, min_requests_to_shard: Optional[int] = None,
                  min_tokens_to_shard: Optional[int] = None, collective_timeout_s: Optional[float] = None,
-                 mirror_host: bool = False, prescore: bool = False):
+                 mirror_host: bool = False, prescore: bool = False, prescore_graphs: bool = True):
         """
         scorer      the HBM-resident predictor
         schedule_type  the reference's schedule string (``opt-...-starv<S>-period<P>``; an ``xpt{path}...``
@@ -134,7 +135,9 @@ class MI355XRanker:
                     (SURVEY.md 8b "Threading") - only collects what is already there.  Arrivals that come while a
                     forward is in flight are batched into the next one.  Same kernels, same scores (up to the batch a
                     request is scored in: the <= 2e-6 of DESIGN.md 4.1b); not with ``group=`` (every rank must make the
-                    same collective calls).  Off by default: the reference scores at the step.
+                    same collective calls).  Off by default: the reference scores at the step.  ``prescore_graphs``: a lone
+                    arrival's forward is replayed from a captured graph (one per 64-token bucket; ~30 us of host time in
+                    the hook instead of the ~0.3 ms its launches take one by one); False: always launch eagerly.
         """
         self.scorer = scorer
         self.device = scorer.device
@@ -182,13 +185,16 @@ class MI355XRanker:
             raise ValueError("prescore=True does not combine with group=: the ranks of a sharded call must make the same "
                              "collective calls, and arrivals are not synchronised across ranks")
         self.prescore = bool(prescore)
+        self.prescore_graphs = bool(prescore_graphs)
+        self._pre_static: Optional[dict] = None
         self._pre_stream = torch.cuda.Stream(self.device) if self.prescore else None
         self._pre_pending: list = []                     # arrivals not yet launched
         self._pre_inflight: collections.deque = collections.deque()    # launched batches, oldest first
         self._pre_free_stagers: list = []
         self._pre_up = _PinnedI32(self.device, 1 << 8) if self.prescore else None
         self._pre_recent: collections.deque = collections.deque()     # issue times of the launches of the last PRESCORE_BURST_S
-        self.stats.update(prescore_launches=0, prescored_requests=0, prescore_wait_seconds=0.0, arrival_hook_seconds=0.0)
+        self.stats.update(prescore_launches=0, prescore_graph_replays=0, prescored_requests=0, prescore_wait_seconds=0.0,
+                          arrival_hook_seconds=0.0)
 
     # ---- construction from the reference's config objects ------------------------------
     @classmethod
@@ -301,13 +307,20 @@ class MI355XRanker:
         arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in batch]
         stager = self._pre_free_stagers.pop() if self._pre_free_stagers else InputStager(self.device, 1 << 12, 1 << 6)
         with torch.cuda.stream(self._pre_stream):
-            ids_dev, cu_dev, cu_host = stager.stage(arrays)
-            scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host, workspace_key="prescore")
+            graph = self._prescore_graph(arrays[0], stager) if len(batch) == 1 and self.prescore_graphs else None
+            if graph is not None:
+                graph.replay()                             # ~30 us of host time instead of ~85 launches
+                scores_dev = self._pre_static["out"]
+            else:
+                ids_dev, cu_dev, cu_host = stager.stage(arrays)
+                scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host, workspace_key="prescore")
             scores_host = stager._sc_h[:len(batch)]
-            scores_host.copy_(scores_dev, non_blocking=True)
+            scores_host.copy_(scores_dev[:len(batch)], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._pre_stream)
-        rec = dict(reqs=batch, scores_dev=scores_dev, scores_host=scores_host, event=ev, stager=stager, left=len(batch))
+        if graph is not None:
+            self.stats["prescore_graph_replays"] += 1
+        rec = dict(reqs=batch, scores_host=scores_host, event=ev, stager=stager, left=len(batch))
         for i, sg in enumerate(batch):
             sg._ltr_pre = (rec, i)
         self._pre_inflight.append(rec)
@@ -315,6 +328,65 @@ class MI355XRanker:
         # batches nobody collected (aborted requests): keep the list bounded
         while len(self._pre_inflight) > 256 and self._pre_inflight[0]["event"].query():
             self._prescore_retire(self._pre_inflight.popleft())
+
+    def _prescore_graph(self, ids: np.ndarray, stager) -> Optional["torch.cuda.CUDAGraph"]:
+        """A one-request forward as a captured graph (the common prescore launch: a lone arrival).  The request is padded
+        to a bucket of ``PRESCORE_GRAPH_BUCKET`` tokens by a second, dummy request (requests do not see each other: the
+        score of the first is what it is alone, up to the <= 2e-6 of the batch it is scored in), so that one graph per bucket
+        serves every prompt length in it.  The graphs share one set of static device buffers and one workspace - every
+        replay runs on the prescore stream, in order; the inputs reach them through this launch's own pinned staging.
+        Called on the prescore stream; stages the inputs and returns the graph to replay, or None (bucket not capturable:
+        the eager path takes over)."""
+        B = self.PRESCORE_GRAPH_BUCKET
+        L = int(ids.shape[0])
+        Tp = (L + 1 + B - 1) // B * B                      # room for the real request and a dummy of >= 1 token
+        st = self._pre_static
+        if st is None:
+            cap = (self.max_length + 1 + B - 1) // B * B
+            st = self._pre_static = dict(cap=cap, ids=torch.empty(cap, dtype=torch.int64, device=self.device),
+                                         cu=torch.empty(3, dtype=torch.int32, device=self.device),
+                                         out=torch.empty(2, dtype=torch.float32, device=self.device), graphs={})
+            self.scorer._workspace(2, cap, "prescore_graph")    # full size now: the graphs hold its address
+        if Tp > st["cap"]:
+            return None
+        g = st["graphs"].get(Tp)
+        if g is False:
+            return None
+        stager._grow(Tp, 2)
+        h_ids, h_cu = stager._ids_h.numpy(), stager._cu_h.numpy()
+        h_ids[:L] = ids
+        h_ids[L] = 2                                       # the dummy: BOS + filler
+        h_ids[L + 1:Tp] = 4
+        h_cu[0], h_cu[1], h_cu[2] = 0, L, Tp
+        ids_d, cu_d = st["ids"][:Tp], st["cu"]
+        ids_d.copy_(stager._ids_h[:Tp], non_blocking=True)
+        cu_d.copy_(stager._cu_h[:3], non_blocking=True)
+        if g is None:
+            try:
+                cu_host = np.array([0, L, Tp], np.int32)
+                # once outside a capture (one-time initialisation inside the library), then captured
+                self.scorer.score_device(ids_d, cu_d, cu_host, out=st["out"], workspace_key="prescore_graph")
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self._pre_stream):
+                    self.scorer.score_device(ids_d, cu_d, cu_host, out=st["out"], workspace_key="prescore_graph")
+            except Exception:      # noqa: BLE001 - a runtime that cannot capture: this bucket stays eager
+                st["graphs"][Tp] = False
+                return None
+            st["graphs"][Tp] = g
+        return g
+
+    def warm_prescore_graphs(self) -> int:
+        """Capture the graph of every bucket now (otherwise each is captured by the first arrival that needs it, a few
+        milliseconds of host time).  Returns the number of graphs."""
+        if not (self.prescore and self.prescore_graphs):
+            return 0
+        B = self.PRESCORE_GRAPH_BUCKET
+        stager = InputStager(self.device, 1 << 12, 1 << 6)
+        with torch.cuda.stream(self._pre_stream):
+            for L in range(B - 1, self.max_length + 1, B):
+                self._prescore_graph(np.full(min(L, self.max_length), 4, np.int64), stager)
+            self._pre_stream.synchronize()
+        return sum(1 for g in self._pre_static["graphs"].values() if g)
 
     def _prescore_retire(self, rec) -> None:
         for sg in rec["reqs"]:
@@ -421,7 +493,8 @@ class MI355XRanker:
                     live_slots=self._live_slots, queue_length=self._n_members,
                     sharded=self._sharded is not None,
                     two_lane_calls=self.scorer.lane_calls() if hasattr(self.scorer, "lane_calls") else 0,
-                    prescore=dict(enabled=self.prescore, launches=st["prescore_launches"], requests=st["prescored_requests"],
+                    prescore=dict(enabled=self.prescore, launches=st["prescore_launches"],
+                                  graph_replays=st["prescore_graph_replays"], requests=st["prescored_requests"],
                                   wait_ms_total=st["prescore_wait_seconds"] * 1e3,
                                   arrival_hook_ms_total=st["arrival_hook_seconds"] * 1e3))
 

@@ -162,7 +162,7 @@ def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max
                 nxt = pending[0].arrival if pending and pending[0].arrival <= t else t
                 lead = min(max(nxt - r.arrival, 0.0), lead_left)
                 if lead > 0:
-                    end = time.perf_counter() + lead
+                    end = h0 + lead                          # the lead counts from the ARRIVAL: the hook's own time is part of it
                     while time.perf_counter() < end:         # (sleep() overshoots by tens of microseconds)
                         pass
                     lead_left -= lead
