@@ -24,9 +24,10 @@ runs in the executor thread (async_llm_engine.py: ``step_async`` -> ``execute_mo
 
 Scoring at arrival (``MI355XRanker(prescore=True)``): a request that arrives at virtual time ``a`` during the
 backbone step is handed to ``add_request`` there and the scheduler step starts at ``t >= a``; the forward has
-``t - a`` of the engine's time to finish.  The replay gives it that lead in REAL time, capped at ``lead_cap_ms``
-per step (6 ms of a 25-ms backbone step: a few one-request forwards; a longer lead changes nothing, a shorter one is
-honoured exactly - the replay never grants more overlap than the trace has).
+``t - a`` of the engine's time to finish.  The replay gives it that lead in REAL time: the gap from each arrival to the
+next one / to the start of the step, each capped at ``lead_cap_ms`` (6 ms of a 25-ms backbone step: a few one-request
+forwards; a longer gap changes nothing, a shorter one is honoured exactly - the replay never grants more overlap than
+the trace has).
 """
 from __future__ import annotations
 
@@ -149,7 +150,7 @@ def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max
             t = pending[0].arrival                           # idle engine: jump to the next arrival
         k = 0
         hook = 0.0
-        lead_left = lead_cap_ms * 1e-3
+        lead_cap = lead_cap_ms * 1e-3
         while pending and pending[0].arrival <= t:
             r = pending.popleft()
             h0 = time.perf_counter()
@@ -157,15 +158,14 @@ def replay(ranker, requests: List[ReplayRequest], backbone_ms: float = 25.0, max
             hook += time.perf_counter() - h0
             sched.waiting.append(r)
             k += 1
-            if prescore and lead_left > 0:
-                # the engine time between this arrival and the next one / the start of the step, in real time (capped)
+            if prescore:
+                # the engine time between this arrival and the next one / the start of the step, in real time (each gap capped)
                 nxt = pending[0].arrival if pending and pending[0].arrival <= t else t
-                lead = min(max(nxt - r.arrival, 0.0), lead_left)
+                lead = min(max(nxt - r.arrival, 0.0), lead_cap)
                 if lead > 0:
                     end = h0 + lead                          # the lead counts from the ARRIVAL: the hook's own time is part of it
                     while time.perf_counter() < end:         # (sleep() overshoots by tens of microseconds)
                         pass
-                    lead_left -= lead
         qlen = len(sched.waiting) + len(sched.running) + len(sched.swapped)
         unscheduled = [g for g in sched.waiting if g.first_scheduled is None]
         if before_step is not None:
