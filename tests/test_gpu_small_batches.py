@@ -140,6 +140,49 @@ def test_scoring_at_arrival_collects_the_same_scores():
     assert rk.metrics()["prescore"]["launches"] == m["launches"]
 
 
+def test_scoring_at_arrival_graph_buckets():
+    """A lone arrival's forward is replayed from a captured graph, one per 64-token bucket, the prompt padded to the bucket
+    by a dummy request (plugin.py `_prescore_graph`).  Prompt lengths around every bucket edge, the shortest and the longest
+    legal prompt: the score equals the ordinary path's (<= 2e-6: the batch a request is scored in), every launch was a
+    replay, and a second request of the same bucket reuses the graph (static buffers, stream-ordered)."""
+    import time
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.tiny_post_ln()
+    ckpt = seeded_checkpoint(spec, 8)
+    sc = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
+    lens = [1, 2, 62, 63, 64, 65, 126, 127, 128, 129, 149, 150, 40, 40, 100]
+    ids, cu = synthetic_batch(spec, lens, 13)
+    mk = lambda: [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(len(lens))]
+    want = np.array(MI355XRanker(sc, "opt", max_length=150).obtain_aux_scores(mk()))
+    rk = MI355XRanker(sc, "opt", max_length=150, prescore=True)
+    assert rk.warm_prescore_graphs() == 3                   # 64 / 128 / 192 tokens (150 + a dummy token)
+    b = mk()
+    for g in b:
+        rk.add_request(g)
+        time.sleep(0.004)                                   # lone arrivals
+    got = np.array(rk.obtain_aux_scores(b))
+    m = rk.metrics()["prescore"]
+    assert m["graph_replays"] == len(lens) and m["requests"] == len(lens), m
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), np.abs(got - want).max()
+    # the same prompts again through the graphs: deterministic
+    c = mk()
+    for g in c:
+        rk.add_request(g)
+        time.sleep(0.004)
+    assert np.array_equal(np.array(rk.obtain_aux_scores(c)), got)
+    # eager fall-back when graphs are off: same scores as the ordinary path's batch-of-one
+    rk2 = MI355XRanker(sc, "opt", max_length=150, prescore=True, prescore_graphs=False)
+    d = mk()
+    for g in d:
+        rk2.add_request(g)
+        time.sleep(0.004)
+    got2 = np.array(rk2.obtain_aux_scores(d))
+    assert rk2.metrics()["prescore"]["graph_replays"] == 0
+    assert np.abs(got2 - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
 def test_concurrent_callers_on_one_handle():
     """Two host threads score different batches on ONE handle at the same time, each with its own workspace, output and
     stream (include/ltr_hip.h allows it; the engine's async loop and a warm-up thread can meet like this).  The handle owns

@@ -383,8 +383,9 @@ class MI355XRanker:
         B = self.PRESCORE_GRAPH_BUCKET
         stager = InputStager(self.device, 1 << 12, 1 << 6)
         with torch.cuda.stream(self._pre_stream):
-            for L in range(B - 1, self.max_length + 1, B):
-                self._prescore_graph(np.full(min(L, self.max_length), 4, np.int64), stager)
+            cap = (self.max_length + 1 + B - 1) // B * B
+            for Tp in range(B, cap + 1, B):                  # the longest prompt of every bucket
+                self._prescore_graph(np.full(min(Tp - 1, self.max_length), 4, np.int64), stager)
             self._pre_stream.synchronize()
         return sum(1 for g in self._pre_static["graphs"].values() if g)
 
