@@ -187,6 +187,7 @@ class MI355XRanker:
         self.prescore = bool(prescore)
         self.prescore_graphs = bool(prescore_graphs)
         self._pre_static: Optional[dict] = None
+        self._pre_ws_key = f"prescore-{id(self):x}"      # scoring scratch of THIS ranker's prescore stream (rankers may share a scorer)
         self._pre_stream = torch.cuda.Stream(self.device) if self.prescore else None
         self._pre_pending: list = []                     # arrivals not yet launched
         self._pre_inflight: collections.deque = collections.deque()    # launched batches, oldest first
@@ -195,6 +196,14 @@ class MI355XRanker:
         self._pre_recent: collections.deque = collections.deque()     # issue times of the launches of the last PRESCORE_BURST_S
         self.stats.update(prescore_launches=0, prescore_graph_replays=0, prescored_requests=0, prescore_wait_seconds=0.0,
                           arrival_hook_seconds=0.0)
+
+    def __del__(self):
+        # the prescore scratch this ranker parked on the (possibly shared) scorer
+        try:
+            for k in (self._pre_ws_key, self._pre_ws_key + "-graph"):
+                self.scorer._ws_by_key.pop(k, None)
+        except Exception:      # noqa: BLE001 - interpreter shutdown / partially constructed object
+            pass
 
     # ---- construction from the reference's config objects ------------------------------
     @classmethod
@@ -313,7 +322,7 @@ class MI355XRanker:
                 scores_dev = self._pre_static["out"]
             else:
                 ids_dev, cu_dev, cu_host = stager.stage(arrays)
-                scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host, workspace_key="prescore")
+                scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host, workspace_key=self._pre_ws_key)
             scores_host = stager._sc_h[:len(batch)]
             scores_host.copy_(scores_dev[:len(batch)], non_blocking=True)
             ev = torch.cuda.Event()
@@ -346,7 +355,7 @@ class MI355XRanker:
             st = self._pre_static = dict(cap=cap, ids=torch.empty(cap, dtype=torch.int64, device=self.device),
                                          cu=torch.empty(3, dtype=torch.int32, device=self.device),
                                          out=torch.empty(2, dtype=torch.float32, device=self.device), graphs={})
-            self.scorer._workspace(2, cap, "prescore_graph")    # full size now: the graphs hold its address
+            self.scorer._workspace(2, cap, self._pre_ws_key + "-graph")    # full size now: the graphs hold its address
         if Tp > st["cap"]:
             return None
         g = st["graphs"].get(Tp)
@@ -365,10 +374,10 @@ class MI355XRanker:
             try:
                 cu_host = np.array([0, L, Tp], np.int32)
                 # once outside a capture (one-time initialisation inside the library), then captured
-                self.scorer.score_device(ids_d, cu_d, cu_host, out=st["out"], workspace_key="prescore_graph")
+                self.scorer.score_device(ids_d, cu_d, cu_host, out=st["out"], workspace_key=self._pre_ws_key + "-graph")
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=self._pre_stream):
-                    self.scorer.score_device(ids_d, cu_d, cu_host, out=st["out"], workspace_key="prescore_graph")
+                    self.scorer.score_device(ids_d, cu_d, cu_host, out=st["out"], workspace_key=self._pre_ws_key + "-graph")
             except Exception:      # noqa: BLE001 - a runtime that cannot capture: this bucket stays eager
                 st["graphs"][Tp] = False
                 return None
