@@ -391,6 +391,8 @@ class MI355XRanker:
             return 0
         B = self.PRESCORE_GRAPH_BUCKET
         stager = InputStager(self.device, 1 << 12, 1 << 6)
+        while len(self._pre_free_stagers) < 4:               # pinned allocations are slow: not in the first arrivals' hooks
+            self._pre_free_stagers.append(InputStager(self.device, 1 << 12, 1 << 6))
         with torch.cuda.stream(self._pre_stream):
             cap = (self.max_length + 1 + B - 1) // B * B
             for Tp in range(B, cap + 1, B):                  # the longest prompt of every bucket
