@@ -11,13 +11,26 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timing: prints latencies / runs traces; ordered LAST so that under -x a flake there "
+                                       "cannot hide a parity test (nothing about wall-clock is asserted anywhere)")
+
+
+# Collection order under `-x`: parity against the reference-generated goldens and the oracle first (rows a1-a14, then the
+# rows §8 marks "next": f1 budget/evictions, f3 hidden-state head, f4 ListMLE / training), then the multi-process tests
+# (they share the one GPU of the box with whatever else runs), then everything marked `timing`.  Round 4 ended red because a
+# latency bound sat in front of test_listmle / test_ltr_head / test_train_step.
+_FILE_ORDER = ["test_oracle_golden.py", "test_host_cpu.py", "test_gpu_rank.py", "test_gpu_attention.py",
+               "test_gpu_gemm_epilogue.py", "test_gpu_scorer.py", "test_gpu_config1.py", "test_gpu_outlier.py",
+               "test_ltr_head.py", "test_listmle.py", "test_train_step.py", "test_gpu_small_batches.py",
+               "test_gpu_full_configs.py", "test_distributed_cpu.py", "test_gpu_distributed.py"]
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests fail loudly (not skip) when selected with -m gpu on a box whose
-    HIP library or device is missing; without -m gpu they are deselected by the
-    driver's -m "not gpu"."""
-    return
+    def key(it):
+        name = os.path.basename(str(it.fspath))
+        pos = _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER) - 2
+        return (1 if it.get_closest_marker("timing") else 0, pos)
+    items.sort(key=key)          # stable: the order inside a file is kept
 
 
 @pytest.fixture(scope="session")
