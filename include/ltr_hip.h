@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LTR_ABI_VERSION 4
+#define LTR_ABI_VERSION 5
 
 enum {
   LTR_OK = 0,
@@ -53,7 +53,19 @@ typedef struct ltr_model_desc {
   int32_t pre_ln;               /* do_layer_norm_before: 1 = 125m style, 0 = 350m style (opt.py:145-176) */
   int32_t weight_dtype;         /* LTR_W_F32: exact f32 MFMA path; LTR_W_F16: fp16 weights x (hi+lo) fp16
                                    split activations, f32 accumulate */
+  int32_t flags;                /* LTR_F_* below; 0 = the production configuration (ABI 5: this word was not there before) */
 } ltr_model_desc;
+
+/* ltr_model_desc.flags (ltr_create; ltr_train_create ignores them).
+ *  LTR_F_NO_LN_FOLD  the GEMMs are fed the bounded LayerNorm OUTPUT by separate LayerNorm launches instead of the folded
+ *                    operand x * gamma * 16 (which must stay inside fp16: LTR_E_RANGE).  The twin handle a caller falls back
+ *                    to when ltr_status reports LTR_E_RANGE for a checkpoint with massive activations (plugin.py).
+ *  LTR_F_NO_LANES    never run a call as two halves on two streams (see "Lanes" below).
+ *  LTR_F_ONE_PASS    F16 mode with ONE fp16 MFMA pass per product: activations rounded to fp16 (the `lo` plane is neither
+ *                    loaded nor multiplied), f32 accumulate - the arithmetic of the reference's own GPU path (fp16 model,
+ *                    vllm/config.py:906-943; train/trainer.py:213-216).  Scores move by ~2e-3 against the fp32 predictor:
+ *                    OUTSIDE the 1e-4 contract of the default mode; opt-in, reported as its own number by bench.py. */
+enum { LTR_F_NO_LN_FOLD = 1, LTR_F_NO_LANES = 2, LTR_F_ONE_PASS = 4 };
 
 /* Order of the device pointers handed to ltr_create (HF tensor names in comments).
  * Matrices / tables are row-major [out, in] in `weight_dtype`; biases, LayerNorm
@@ -119,6 +131,17 @@ int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens);
  * their own, and ltr_workspace_bytes accounts for the second set of activations (a smaller workspace is not an error: the
  * call then runs on one lane).  ltr_lane_calls: how many calls on this handle have run on two lanes (monitoring, tests). */
 int64_t ltr_lane_calls(ltr_handle h);
+/* Whether the two lanes really run side by side is a property of the PROCESS: the HIP runtime multiplexes all streams of a
+ * process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a lane stream that lands on the hardware queue of
+ * the caller's stream runs its half AFTER the caller's, slower than one lane.  ltr_create therefore probes (two ~20 us spin
+ * kernels, one per stream, fork / join) and keeps a lane stream only if it overlaps with `stream`; candidates are tried at
+ * normal, then at high priority (a queue of its own class); when none overlaps the handle runs on one lane.  A call made
+ * while `stream` is being captured into a graph also runs on one lane (the split is taken from the HOST copy of cu_seqlens,
+ * which a replay would freeze).
+ * ltr_lane_probe repeats the measurement on any stream (synchronises it): solo_us = one spin kernel on `stream`,
+ * pair_us = one on each stream between fork and join (pair_us ~ solo_us: concurrent; ~ 2 x: the streams alias);
+ * returns the number of candidate streams ltr_create tried (0: the handle has no lane stream; negative LTR_E_* on error). */
+int ltr_lane_probe(ltr_handle h, void* stream, float* solo_us, float* pair_us);
 
 /* The predictor forward for a flat varlen batch: replaces one drain of the AUX
  * engine, i.e. AUXLLMEngine.obtain_aux_scores' step loop (vllm/engine/
@@ -151,8 +174,9 @@ int ltr_score(ltr_handle h, const int64_t* token_ids, const int32_t* cu_seqlens,
  * such an id (LTR_OK otherwise) and clears the flag.  Call it wherever the scores are read.
  * LTR_E_RANGE: the residual stream of an F16-mode pre-LN model exceeded what the LayerNorm-fold
  * operand can carry in fp16 (|x * gamma| > 4094; the reference's own fp16 GPU path overflows at
- * |x| > 65504): the scores of that call are invalid; a handle created with LTR_NO_LN_FOLD=1 in
- * the environment feeds the GEMMs the bounded LayerNorm output instead. */
+ * |x| > 65504): the scores of that call are invalid; a handle created with LTR_F_NO_LN_FOLD
+ * feeds the GEMMs the bounded LayerNorm output instead (MI355XRanker re-scores the batch on such
+ * a twin handle and carries on). */
 int ltr_status(ltr_handle h, void* stream);
 
 /* Same forward stopped after `n_layers` decoder layers (n_layers < 0: all), writing the

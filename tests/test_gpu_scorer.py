@@ -570,10 +570,34 @@ def test_layernorm_fold_operand_overflow_is_reported(dev, monkeypatch):
     want_near = OracleOPTScorer(spec, near, dtype=torch.float64).score(ids, cu)
     got_near = _scorer(spec, near, dev, "f16").score(ids, cu)
     assert np.isfinite(got_near).all() and np.abs(got_near - want_near).max() <= 1e-4 * max(1.0, np.abs(want_near).max())
-    monkeypatch.setenv("LTR_NO_LN_FOLD", "1")
-    got = _scorer(spec, ckpt, dev, "f16").score(ids, cu)
     want = OracleOPTScorer(spec, ckpt, dtype=torch.float64).score(ids, cu)
-    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    tol = 1e-4 * max(1.0, np.abs(want).max())
+    # the handle flag (what a caller passes): LTR_F_NO_LN_FOLD through HipOPTScorer(ln_fold=False)
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    got = HipOPTScorer(spec, ckpt, str(dev), "f16", ln_fold=False).score(ids, cu)
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= tol
+    # the serving plug-in does not raise through schedule() -> step() (llm_engine.py:569 would end the engine): it re-scores
+    # the batch on the unfolded twin handle, counts the fallback and stays on the twin
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+    for prescore in (False, True):
+        rk = MI355XRanker(_scorer(spec, ckpt, dev, "f16"), "opt", max_length=150, prescore=prescore)
+        groups = [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(len(cu) - 1)]
+        if prescore:
+            for g in groups[:2]:
+                rk.add_request(g)
+        got = np.array(rk.obtain_aux_scores(groups))
+        assert np.abs(got - want).max() <= tol, (prescore, got, want)
+        assert rk.metrics()["range_fallbacks"] == 1 and rk.scorer.ln_fold is False
+        assert [int(g.request_id) for g in rk.order(groups)] == sorted(range(len(groups)), key=lambda i: -got[i])
+        more = [FakeSeqGroup(f"m{i}", ids[cu[i]:cu[i + 1]].tolist()) for i in range(len(cu) - 1)]
+        if prescore:
+            rk.add_request(more[0])
+        got2 = np.array(rk.obtain_aux_scores(more))            # later calls run on the twin: no second fallback
+        assert np.abs(got2 - want).max() <= tol and rk.metrics()["range_fallbacks"] == 1
+    monkeypatch.setenv("LTR_NO_LN_FOLD", "1")                  # the environment switch (diag) still works
+    got = _scorer(spec, ckpt, dev, "f16").score(ids, cu)
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= tol
 
 
 @pytest.mark.parametrize("variant,expected,mode", [("st", "expected_class2", "f16"), ("sharded", "expected_class2", "f16"),

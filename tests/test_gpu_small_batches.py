@@ -183,6 +183,43 @@ def test_scoring_at_arrival_graph_buckets():
     assert np.abs(got2 - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max()))
 
 
+@pytest.mark.parametrize("warm", [False, True])
+def test_scoring_at_arrival_graph_buckets_in_the_two_lane_range(warm):
+    """Buckets of >= 1,216 tokens fall into the range where an eager call runs as two halves on two streams, split at a point
+    taken from the HOST copy of cu_seqlens - which a graph would freeze at the first arrival's length (a
+    later, longer prompt of the same bucket then read rows that were never computed).  A call that is being captured runs on
+    one lane (ltr_api.hip run_forward), so one graph serves every length of its bucket: a shorter prompt first and a longer
+    one after it, and the other way round, lazily captured and warmed, against the ordinary path and the oracle."""
+    import dataclasses
+    import time
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = dataclasses.replace(OPTSpec.tiny_pre_ln(), max_position_embeddings=2048)
+    ckpt = seeded_checkpoint(spec, 21)
+    sc = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
+    lens = [1220, 1275, 1279, 1216, 1340, 1290, 1281, 2047, 1990, 2048, 1985, 70]   # buckets 1280, 1344, 2048, 2112 (+ a small one)
+    ids, cu = synthetic_batch(spec, lens, 17)
+    mk = lambda: [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(len(lens))]
+    plain = MI355XRanker(sc, "opt", max_length=2048)
+    want = np.array([plain.obtain_aux_scores([g])[0] for g in mk()])          # each request scored alone, eagerly
+    orc = OracleOPTScorer(spec, ckpt).score(ids, cu)
+    assert np.abs(want - orc).max() <= TOL
+    rk = MI355XRanker(sc, "opt", max_length=2048, prescore=True)
+    if warm:
+        assert rk.warm_prescore_graphs() == (2048 + 1 + 63) // 64
+    b = mk()
+    for g in b:
+        rk.add_request(g)
+        time.sleep(0.02)                                                       # lone arrivals
+    got = np.array(rk.obtain_aux_scores(b))
+    m = rk.metrics()["prescore"]
+    assert m["graph_replays"] == len(lens), m
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (got - want)
+    assert np.abs(got - orc).max() <= TOL
+    sc.check_status()
+
+
 def test_concurrent_callers_on_one_handle():
     """Two host threads score different batches on ONE handle at the same time, each with its own workspace, output and
     stream (include/ltr_hip.h allows it; the engine's async loop and a warm-up thread can meet like this).  The handle owns

@@ -20,13 +20,13 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 
 # every symbol include/ltr_hip.h declares (tests check the library exports them all)
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
-           "ltr_set_chunk_tokens", "ltr_lane_calls", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
+           "ltr_set_chunk_tokens", "ltr_lane_calls", "ltr_lane_probe", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
            "ltr_train_step", "ltr_train_read", "ltr_attention", "ltr_train_attention",
            "ltr_train_attention_workspace_bytes")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 LTR_E_INVAL, LTR_E_RANGE = -22, -34
@@ -43,7 +43,10 @@ class LtrError(RuntimeError):
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "hidden_size", "ffn_dim", "num_layers", "num_heads", "word_embed_proj_dim",
-        "pos_rows", "num_labels", "pre_ln", "weight_dtype")]
+        "pos_rows", "num_labels", "pre_ln", "weight_dtype", "flags")]
+
+
+LTR_F_NO_LN_FOLD, LTR_F_NO_LANES, LTR_F_ONE_PASS = 1, 2, 4
 
 
 class HeadDesc(C.Structure):
@@ -107,6 +110,7 @@ def _load() -> C.CDLL:
     lib.ltr_set_chunk_tokens.argtypes = [vp, i32]
     lib.ltr_lane_calls.argtypes = [vp]
     lib.ltr_lane_calls.restype = C.c_int64
+    lib.ltr_lane_probe.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ltr_score.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.ltr_forward_hidden.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.ltr_embed_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
@@ -135,7 +139,7 @@ def _load() -> C.CDLL:
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version", "ltr_train_workspace_bytes",
-                        "ltr_train_attention_workspace_bytes"):
+                        "ltr_train_attention_workspace_bytes", "ltr_lane_calls"):
             fn.restype = C.c_int
     if lib.ltr_abi_version() != ABI_VERSION:
         raise LtrError(f"{LIB_PATH} has ABI version {lib.ltr_abi_version()}, this binding needs {ABI_VERSION}: rebuild")

@@ -74,6 +74,12 @@ struct ltr_model {
   hipEvent_t lane_fork = nullptr, lane_join = nullptr;
   std::mutex lane_mu;
   std::atomic<int64_t> lane_calls{0};
+  int lane_tries = 0;              // candidate streams ltr_create probed before it kept one (ltr_lane_probe reports it)
+  // caller streams the lane stream has been probed against (guarded by lane_mu): (stream, runs beside it).  ltr_create
+  // probes against ITS stream; a call on another stream (a prescore side stream, a worker thread's stream) probes once,
+  // on its first lane-sized call (one host synchronisation of that stream, ~0.1 ms).
+  std::vector<std::pair<hipStream_t, bool>> lane_seen;
+  bool one_pass = false;           // LTR_F_ONE_PASS: the GEMMs / attention multiply the hi plane only
   ~ltr_model() {
     if (lane_stream) (void)hipStreamDestroy(lane_stream);
     if (lane_fork) (void)hipEventDestroy(lane_fork);
@@ -449,6 +455,57 @@ int ChunkRun::layer(const int L) {
   return LTR_OK;
 }
 
+// ---- lane-stream probe.  Two streams of a process run side by side only if the runtime mapped them to different hardware
+// queues (GPU_MAX_HW_QUEUES, 4 by default, shared by every stream of the process); on the same queue the lane's half runs
+// after the caller's - slower than one lane (GPUTEST_r04: k = 64 in 3.93 ms in a process with dozens of handles, 2.91 in
+// bench.py).  A spin of SPIN_TICKS of the 100 MHz wall clock on each stream between fork and join tells the two cases apart.
+constexpr long long SPIN_TICKS = 2000;   // 20 us
+__global__ void lane_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// solo_us: one spin on s; pair_us: one on s and one on lane between fork and join (events on s around both)
+int lane_probe(hipStream_t s, hipStream_t lane, hipEvent_t fork, hipEvent_t join, float* solo_us, float* pair_us) {
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    set_error("lane probe: cannot create events");
+    return LTR_E_HIP;
+  }
+  int rc = LTR_OK;
+  auto run = [&]() -> int {
+    lane_spin_kernel<<<1, 64, 0, s>>>(200);                      // warm both streams (code object load, queue creation)
+    LTR_HIP_CHECK(hipEventRecord(fork, s));
+    LTR_HIP_CHECK(hipStreamWaitEvent(lane, fork, 0));
+    lane_spin_kernel<<<1, 64, 0, lane>>>(200);
+    LTR_HIP_CHECK(hipEventRecord(join, lane));
+    LTR_HIP_CHECK(hipStreamWaitEvent(s, join, 0));
+    LTR_HIP_CHECK(hipEventRecord(e0, s));
+    lane_spin_kernel<<<1, 64, 0, s>>>(SPIN_TICKS);
+    LTR_HIP_CHECK(hipEventRecord(e1, s));
+    LTR_HIP_CHECK(hipEventRecord(fork, s));
+    LTR_HIP_CHECK(hipStreamWaitEvent(lane, fork, 0));
+    lane_spin_kernel<<<1, 64, 0, s>>>(SPIN_TICKS);
+    lane_spin_kernel<<<1, 64, 0, lane>>>(SPIN_TICKS);
+    LTR_HIP_CHECK(hipEventRecord(join, lane));
+    LTR_HIP_CHECK(hipStreamWaitEvent(s, join, 0));
+    LTR_HIP_CHECK(hipEventRecord(e2, s));
+    LTR_HIP_CHECK(hipEventSynchronize(e2));
+    float a = 0.f, b = 0.f;
+    LTR_HIP_CHECK(hipEventElapsedTime(&a, e0, e1));
+    LTR_HIP_CHECK(hipEventElapsedTime(&b, e1, e2));
+    *solo_us = a * 1e3f; *pair_us = b * 1e3f;
+    return LTR_OK;
+  };
+  rc = run();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  return rc;
+}
+inline bool lanes_overlap(float solo_us, float pair_us) { return pair_us < 1.6f * solo_us; }
+
 int check_desc(const ltr_model_desc& d) {
   if (d.hidden_size <= 0 || d.num_heads <= 0 || d.hidden_size != d.num_heads * 64) {
     set_error("ltr_create: head size must be 64 (H=%d, heads=%d)", d.hidden_size, d.num_heads);
@@ -466,6 +523,14 @@ int check_desc(const ltr_model_desc& d) {
   }
   if (d.num_labels < 1 || d.num_layers < 0 || d.vocab_size < 1 || d.pos_rows < 3) {
     set_error("ltr_create: bad num_labels/num_layers/vocab/pos_rows");
+    return LTR_E_INVAL;
+  }
+  if (d.flags & ~(LTR_F_NO_LN_FOLD | LTR_F_NO_LANES | LTR_F_ONE_PASS)) {
+    set_error("ltr_create: unknown flags 0x%x (a caller built against ABI 4 leaves this word uninitialised)", d.flags);
+    return LTR_E_INVAL;
+  }
+  if ((d.flags & LTR_F_ONE_PASS) && d.weight_dtype != LTR_W_F16) {
+    set_error("ltr_create: LTR_F_ONE_PASS exists in F16 mode only");
     return LTR_E_INVAL;
   }
   return LTR_OK;
@@ -540,13 +605,35 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
     return LTR_E_NOMEM;
   }
   { const char* e = getenv("LTR_DEBUG_ATTN_VALU"); m->dbg_attn_valu = e && e[0] == '1'; }
-  if (lanes_mode() > 0 && desc->weight_dtype == LTR_W_F16) {     // second lane for mid-sized batches (run_forward); optional
-    if (hipStreamCreateWithFlags(&m->lane_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->lane_join, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      if (m->lane_stream) { (void)hipStreamDestroy(m->lane_stream); m->lane_stream = nullptr; }
+  m->one_pass = (desc->flags & LTR_F_ONE_PASS) != 0;
+  if (lanes_mode() > 0 && desc->weight_dtype == LTR_W_F16 && !(desc->flags & LTR_F_NO_LANES)) {
+    // second lane for mid-sized batches (run_forward); optional.  Keep a candidate only if it runs BESIDE `stream` (lane_probe):
+    // up to three streams at normal priority, then one at the highest priority (its own hardware-queue class).  Rejected
+    // candidates stay alive until the choice is made, so that the next one is mapped to another queue.  LTR_LANE_PROBE=0
+    // keeps the first candidate unprobed (the round-4 behaviour; lab).
+    static const bool probe_on = [] { const char* e = getenv("LTR_LANE_PROBE"); return !(e && e[0] == '0'); }();
+    if (hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&m->lane_join, hipEventDisableTiming) == hipSuccess) {
+      int lo_pri = 0, hi_pri = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+      std::vector<hipStream_t> rejected;
+      for (int attempt = 0; attempt < 4 && !m->lane_stream; ++attempt) {
+        hipStream_t cand = nullptr;
+        const hipError_t e = attempt < 3 ? hipStreamCreateWithFlags(&cand, hipStreamNonBlocking)
+                                         : hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, hi_pri);
+        if (e != hipSuccess) { (void)hipGetLastError(); break; }
+        m->lane_tries = attempt + 1;
+        float solo = 0.f, pair = 0.f;
+        if (!probe_on || (lane_probe(cs, cand, m->lane_fork, m->lane_join, &solo, &pair) == LTR_OK && lanes_overlap(solo, pair))) {
+          m->lane_stream = cand;
+          if (probe_on) m->lane_seen.emplace_back(cs, true);
+        }
+        else
+          rejected.push_back(cand);
+      }
+      for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
     }
+    (void)hipGetLastError();
   }
   m->wg = m->w;
   if (desc->weight_dtype == LTR_W_F16) {
@@ -613,11 +700,12 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
   {
     // LayerNorm fold: pre-LN blocks in F16 mode with H a multiple of 64 (LTR_NO_LN_FOLD=1 keeps the LayerNorm
     // launches: A/B switch for measurements and debugging)
-    const char* e = getenv("LTR_NO_LN_FOLD");
+    const char* e = getenv("LTR_NO_LN_FOLD");               // (diag; callers use LTR_F_NO_LN_FOLD)
+    const bool no_fold = (e && e[0] == '1') || (desc->flags & LTR_F_NO_LN_FOLD);
     const size_t H = desc->hidden_size, F = desc->ffn_dim;
     // pre-LN (125m): LN1 rides on QKV, LN2 on fc1.  Post-LN (350m): this layer's LN1 (after the attention residual)
     // rides on fc1, the PREVIOUS layer's LN2 on QKV; the residuals are rebuilt by the RLN epilogue (ChunkRun::layer).
-    m->ln_fold = desc->weight_dtype == LTR_W_F16 && H % 64 == 0 && desc->num_layers > 0 && !(e && e[0] == '1');
+    m->ln_fold = desc->weight_dtype == LTR_W_F16 && H % 64 == 0 && desc->num_layers > 0 && !no_fold;
     if (m->ln_fold) {
       const size_t per_layer = 2 * (3 * H + F);
       if (hipMalloc((void**)&m->fold, per_layer * desc->num_layers * sizeof(float)) != hipSuccess) {
@@ -664,13 +752,23 @@ int ltr_status(ltr_handle h, void* stream) {
                 "vocab_parallel_embedding.py:95-106); the scores of that call are invalid", h->d.vocab_size);
     else
       set_error("ltr_score: the residual stream left the fp16 range of the LayerNorm-fold operand (|x * gamma| > 4094); "
-                "the scores of that call are invalid - create the handle with LTR_NO_LN_FOLD=1 for this checkpoint");
+                "the scores of that call are invalid - score the batch on a handle created with LTR_F_NO_LN_FOLD");
     return (flag & 1) ? LTR_E_INVAL : LTR_E_RANGE;
   }
   return LTR_OK;
 }
 
 int64_t ltr_lane_calls(ltr_handle h) { return h ? h->lane_calls.load(std::memory_order_relaxed) : 0; }
+
+int ltr_lane_probe(ltr_handle h, void* stream, float* solo_us, float* pair_us) {
+  if (!h || !solo_us || !pair_us) { set_error("ltr_lane_probe: NULL argument"); return LTR_E_INVAL; }
+  *solo_us = *pair_us = 0.f;
+  if (!h->lane_stream) return 0;
+  DeviceGuard guard(h->device);
+  std::lock_guard<std::mutex> lk(h->lane_mu);          // the fork / join events belong to calls that hold this lock
+  const int rc = lane_probe((hipStream_t)stream, h->lane_stream, h->lane_fork, h->lane_join, solo_us, pair_us);
+  return rc ? rc : h->lane_tries;
+}
 
 int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens) {
   if (!h || chunk_tokens < 0) { set_error("ltr_set_chunk_tokens: bad argument"); return LTR_E_INVAL; }
@@ -819,7 +917,13 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     // independent (a request never reads another request's state), so one half's under-filled launches run beside the
     // other's.  Each half is exactly the call one would make for it alone (same kernels, same results).
     int r_mid = -1;
-    if (!hidden_out && r0 == 0 && r1 == N && N >= 2 && h->lane_stream && lanes_for_tokens(t1 - t0)) {
+    bool capturing = false;            // a captured call must not depend on the host copy of cu_seqlens beyond (N, T): one lane
+    if (h->lane_stream) {
+      hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cst) != hipSuccess) (void)hipGetLastError();
+      capturing = cst != hipStreamCaptureStatusNone;
+    }
+    if (!hidden_out && r0 == 0 && r1 == N && N >= 2 && h->lane_stream && !capturing && lanes_for_tokens(t1 - t0)) {
       const int64_t half = (t1 - t0) / 2;
       r_mid = 1;
       while (r_mid + 1 < N && cu[r_mid + 1] - t0 <= half) ++r_mid;              // first cut at or past the middle ...
@@ -827,6 +931,18 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     }
     std::unique_lock<std::mutex> lane_lock(h->lane_mu, std::defer_lock);
     if (r_mid > 0 && !lane_lock.try_lock()) r_mid = -1;
+    if (r_mid > 0) {                   // does the lane stream run beside THIS caller stream?  (probed once per stream)
+      static const bool probe_on = [] { const char* e = getenv("LTR_LANE_PROBE"); return !(e && e[0] == '0'); }();
+      bool known = !probe_on, ok = true;
+      for (auto& e : h->lane_seen) if (e.first == s) { known = true; ok = e.second; }
+      if (!known) {
+        float solo = 0.f, pair = 0.f;
+        ok = lane_probe(s, h->lane_stream, h->lane_fork, h->lane_join, &solo, &pair) == LTR_OK && lanes_overlap(solo, pair);
+        if (h->lane_seen.size() >= 16) h->lane_seen.erase(h->lane_seen.begin());
+        h->lane_seen.emplace_back(s, ok);
+      }
+      if (!ok) { r_mid = -1; lane_lock.unlock(); }
+    }
     if (r_mid > 0) {
       const int tm_ = cu[r_mid];
       Workspace wa = carve(d, tm_ - t0, r_mid - r0, workspace, h->ln_fold, head_mode(h));

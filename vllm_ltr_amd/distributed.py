@@ -15,6 +15,20 @@ deterministic rank step.  One process per GPU, ``torch.distributed`` (backend "n
 All ranks derive the shard map from the same ``cu_seqlens`` and take the shard-or-not decision from
 the same (N, T), so the collective can never be mismatched (SURVEY.md section 5 'failure
 detection'); a peer that never arrives is bounded by ``timeout_s`` (every surviving rank raises).
+
+Two ways to drive it:
+
+* SPMD (``score`` / ``score_device``): every rank makes the same call with the same batch (bench.py's default; an
+  engine that replicates its scheduler).
+* driver / workers (``score_from_driver`` on the rank that owns the scheduler, ``serve()`` on the others) - what a
+  vllm-ltr engine looks like: only the DRIVER has a scheduler, the workers are told what to run and are sent the
+  inputs (ray_gpu_executor.py:440-523 ``_run_aux_workers``, worker_base.py:151-166 ``execute_aux_method``,
+  worker.py:234-236 + model_runner.py:760-807 ``broadcast_tensor_dict``).  Here the driver sends a 16-byte header
+  (opcode, N, tokens per payload, requests per payload) by broadcast and each worker ITS shard only - cu_seqlens slice
+  and token ids packed into one int64 payload - by ONE scatter: xGMI is a full mesh of point-to-point links, so the
+  seven payloads of an 8-GPU node leave the driver on seven links at once (T / 8 ids per link) where the reference's
+  broadcast moves all T ids to every worker.  Then shard -> score -> the same all-gather of scores.  A call below
+  the shard threshold involves no worker at all: the driver scores alone, nothing is sent.
 """
 from __future__ import annotations
 
@@ -30,7 +44,13 @@ ONE_PASS_TOKENS = 196608
 
 
 class PeerTimeout(RuntimeError):
-    """A collective of the sharded scoring call did not complete within ``timeout_s``: a peer rank is gone or stuck."""
+    """A collective of the sharded scoring call did not complete within ``timeout_s``: a peer rank is gone or stuck.
+    The communicator is NOT usable afterwards (the abandoned collective is still enqueued on it): the surviving ranks must
+    destroy the process group and build a new one before they score together again."""
+
+
+# opcodes of the driver's header (ShardedScorer.score_from_driver / serve_once)
+OP_STOP, OP_SCORE, OP_SCORE_UNFOLDED = 0, 1, 2
 
 
 def shard_bounds(cu_seqlens: np.ndarray, world: int) -> List[Tuple[int, int]]:
@@ -73,7 +93,7 @@ class _GatherBuffers:
 
 
 def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None, out: Optional[torch.Tensor] = None,
-                  bufs: Optional[_GatherBuffers] = None, wait=None) -> torch.Tensor:
+                  bufs: Optional[_GatherBuffers] = None, wait=None, compact: bool = True) -> Optional[torch.Tensor]:
     """All-gather variable-length f32 score shards: padded to the buffer capacity, one
     ``all_gather_into_tensor``, one compaction.  ``counts[r]`` = shard length of rank r (known to every
     rank).  ``out`` f32 [sum(counts)]: the compaction writes straight into it (the queue's score slots).
@@ -98,6 +118,8 @@ def gather_scores(local: torch.Tensor, counts: Sequence[int], group=None, out: O
         bufs.recv.copy_(bufs.recv_h, non_blocking=True)
     else:
         wait(dist.all_gather_into_tensor(bufs.recv, bufs.send, group=group, async_op=True))
+    if not compact:                      # a worker of the driver / workers mode: it only feeds the collective
+        return None
     g = bufs.recv.view(world, cap)
     parts = [g[r, :counts[r]] for r in range(world) if counts[r]]
     if out is not None:
@@ -117,11 +139,15 @@ class ShardedScorer:
     Below it rank 0 scores alone and broadcasts.
     min_requests_to_shard: alternative rule on the request count (when given it replaces the token rule).
     timeout_s: upper bound for every collective of a call; on expiry :class:`PeerTimeout` is raised on every rank that
-    is still alive (None: the process group's own timeout).
+    is still alive (None: the process group's own timeout).  Cost: with the RCCL backend ``work.wait(timeout)`` blocks
+    the HOST until the collective has finished (without a timeout it only orders the stream), so every sharded call
+    then contains host synchronisations - irrelevant beside a >= 196,608-token forward, but it is there.  After a
+    :class:`PeerTimeout` the process group must be destroyed and re-created.
+    driver_rank: rank (of the group) that owns the scheduler in the driver / workers mode.
     """
 
     def __init__(self, scorer, device, group=None, min_requests_to_shard: Optional[int] = None,
-                 min_tokens_to_shard: Optional[int] = None, timeout_s: Optional[float] = None):
+                 min_tokens_to_shard: Optional[int] = None, timeout_s: Optional[float] = None, driver_rank: int = 0):
         import torch.distributed as dist
         self.dist = dist
         self.scorer = scorer if hasattr(scorer, "score_device") else None
@@ -136,6 +162,14 @@ class ShardedScorer:
         self.timeout_s = timeout_s
         self._bufs = _GatherBuffers(self.device, self.world, self.device.type == "cuda" and self.backend != "nccl")
         self._flag = None
+        # driver / workers mode
+        self.driver_rank = int(driver_rank)
+        self.unfolded = False                  # driver: the next header tells the workers to switch to their unfolded twins
+        self.last_call_collective = False      # driver: did the last score_from_driver involve the workers?
+        self._hdr = None
+        self._payload = None                   # int64 [world, words] (driver) / [words] (worker), grown on demand
+        self._payload_h = None
+        self.calls_served = 0
 
     def shards(self, n: int, tokens: int) -> bool:
         """The shard-or-not decision; a function of (n, T) only, so every rank takes the same one."""
@@ -172,6 +206,140 @@ class ShardedScorer:
 
     def any_rank(self, flag: bool) -> bool:
         return self.agree_status(1 if flag else 0) != 0
+
+    # ---- driver / workers mode -------------------------------------------------------------------------------------
+    def _src(self) -> int:
+        return self.dist.get_global_rank(self.group, self.driver_rank) if self.group else self.driver_rank
+
+    def _on_device(self) -> bool:
+        return self.backend == "nccl"
+
+    def _bcast_header(self, values=None):
+        """int32 [4] = (opcode, N, payload token capacity, payload request capacity) from the driver.  NOT bounded by
+        ``timeout_s`` on the workers: a worker waits here for as long as the engine has nothing to score."""
+        if self._hdr is None:
+            self._hdr = torch.zeros(4, dtype=torch.int32, device=self.device if self._on_device() else "cpu")
+        if values is not None:
+            self._hdr.copy_(torch.tensor(values, dtype=torch.int32))
+            self._wait(self.dist.broadcast(self._hdr, src=self._src(), group=self.group, async_op=True))
+            return values
+        self.dist.broadcast(self._hdr, src=self._src(), group=self.group)
+        return [int(v) for v in self._hdr.tolist()]
+
+    def _payload_buf(self, words: int, rows: int):
+        need = rows * words
+        if self._payload is None or self._payload.numel() < need:
+            self._payload = torch.empty(max(need, 1 << 16), dtype=torch.int64, device=self.device)
+            if not self._on_device() and self.device.type == "cuda":
+                self._payload_h = torch.empty(self._payload.numel(), dtype=torch.int64, pin_memory=True)
+        return self._payload[:need].view(rows, words)
+
+    def _scatter(self, recv: torch.Tensor, rows: Optional[torch.Tensor]):
+        """One scatter of equal-sized int64 payloads from the driver (RCCL on device buffers; staged through the host for
+        the one-device gloo dry run)."""
+        src = self._src()
+        if recv.is_cuda and not self._on_device():
+            h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+            h_rows = list(rows.cpu().unbind(0)) if rows is not None else None
+            self._wait(self.dist.scatter(h_recv, h_rows, src=src, group=self.group, async_op=True))
+            recv.copy_(h_recv)
+        else:
+            self._wait(self.dist.scatter(recv, list(rows.unbind(0)) if rows is not None else None, src=src,
+                                         group=self.group, async_op=True))
+
+    @staticmethod
+    def _payload_words(cap_tokens: int, cap_reqs: int) -> int:
+        return 2 + (cap_reqs + 1) + cap_tokens          # [n, t, cu_0 .. cu_n (relative), pad, ids_0 .. ids_{t-1}, pad]
+
+    def score_from_driver(self, ids_dev: torch.Tensor, cu_dev: torch.Tensor, cu_host: np.ndarray,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Called by the DRIVER only (the rank whose scheduler asked for scores); the other ranks sit in :meth:`serve`.
+        Below the shard threshold the driver scores alone and no worker is involved.  Above it: header broadcast, one
+        scatter of per-rank payloads (each worker gets the cu_seqlens slice and the token ids of ITS shard, nothing
+        else), every rank scores its shard, one all-gather of the scores; ``last_call_collective`` tells the caller that
+        the status agreement (:meth:`agree_status`) has a partner on the workers."""
+        assert self.scorer is not None and self.rank == self.driver_rank
+        cu = np.asarray(cu_host, dtype=np.int64)
+        n = cu.shape[0] - 1
+        self.last_call_collective = False
+        if n <= 0:
+            return torch.zeros(0, dtype=torch.float32, device=self.device)
+        if not self.shards(n, int(cu[-1])):
+            return self.scorer.score_device(ids_dev, cu_dev, np.ascontiguousarray(cu_host, np.int32), out=out)
+        bounds = shard_bounds(cu, self.world)
+        counts = [b - a for a, b in bounds]
+        cap_reqs = max(counts)
+        cap_tokens = max(int(cu[b] - cu[a]) for a, b in bounds)
+        words = self._payload_words(cap_tokens, cap_reqs)
+        self._bcast_header([OP_SCORE_UNFOLDED if self.unfolded else OP_SCORE, n, cap_tokens, cap_reqs])
+        rows = self._payload_buf(words, self.world)
+        cu64 = cu_dev.to(torch.int64)
+        for r, (a, b) in enumerate(bounds):            # ~3 small device copies per rank, beside a >= 196,608-token forward
+            if r == self.rank:
+                continue                               # (the driver scores its shard from the batch itself)
+            t0, t1 = int(cu[a]), int(cu[b])
+            row = rows[r]
+            row[0], row[1] = b - a, t1 - t0
+            torch.sub(cu64[a:b + 1], t0, out=row[2:2 + (b - a) + 1])
+            row[3 + cap_reqs:3 + cap_reqs + (t1 - t0)].copy_(ids_dev[t0:t1])
+        mine = torch.empty(words, dtype=torch.int64, device=self.device)
+        self._scatter(mine, rows)
+        self.last_call_collective = True
+        self.calls_served += 1
+
+        def local(r0, r1, out_l):
+            t0 = int(cu[r0])
+            cu_s = (cu[r0:r1 + 1] - t0).astype(np.int32)
+            cu_d = cu_dev[r0:r1 + 1] - t0 if t0 else cu_dev[r0:r1 + 1]
+            return self.scorer.score_device(ids_dev[t0:int(cu[r1])], cu_d.contiguous(), cu_s, out=out_l)
+        return self._exchange(n, True, bounds, local, None, out=out)
+
+    def serve_once(self) -> bool:
+        """One iteration of a WORKER's loop: wait for the driver's header, receive this rank's payload, score it, take
+        part in the all-gather and in the status agreement.  Returns False when the driver said stop."""
+        assert self.scorer is not None and self.rank != self.driver_rank
+        op, n, cap_tokens, cap_reqs = self._bcast_header()
+        if op == OP_STOP:
+            return False
+        if op == OP_SCORE_UNFOLDED and getattr(self.scorer, "ln_fold", False):
+            self.scorer = self.scorer.unfolded_twin()
+        words = self._payload_words(cap_tokens, cap_reqs)
+        mine = self._payload_buf(words, 1)[0]
+        self._scatter(mine, None)
+        head = mine[:3 + cap_reqs].cpu()                       # n, t and the relative cu_seqlens of my shard (one small D2H)
+        n_r, t_r = int(head[0]), int(head[1])
+        self._bufs.ensure(max(cap_reqs, 1))
+        if n_r:
+            cu_s = head[2:2 + n_r + 1].numpy().astype(np.int32)
+            cu_d = mine[2:2 + n_r + 1].to(torch.int32)
+            ids_d = mine[3 + cap_reqs:3 + cap_reqs + t_r]
+            local = self.scorer.score_device(ids_d, cu_d, cu_s, out=self._bufs.send[:n_r])
+        else:
+            local = self._bufs.send[:0]
+        # the workers do not need the scores: they only feed the all-gather (same buffers, same capacity on every rank)
+        gather_scores(local, [cap_reqs] * self.world, self.group, out=None, bufs=self._bufs, wait=self._wait,
+                      compact=False)
+        mine_status = 0
+        try:
+            if hasattr(self.scorer, "check_status"):
+                self.scorer.check_status()
+        except Exception as e:          # noqa: BLE001 - the code travels to the driver, which raises / falls back for all
+            mine_status = 2 if getattr(e, "code", 0) == -34 else 1
+        self.agree_status(mine_status)
+        self.calls_served += 1
+        return True
+
+    def serve(self) -> int:
+        """The worker loop (what worker_base.py:151-166 ``execute_aux_method`` is to the reference's workers): returns the
+        number of calls served when the driver sends the stop opcode (:meth:`stop_workers`)."""
+        while self.serve_once():
+            pass
+        return self.calls_served
+
+    def stop_workers(self) -> None:
+        """Driver: end every worker's :meth:`serve` loop."""
+        if self.world > 1 and self.rank == self.driver_rank:
+            self._bcast_header([OP_STOP, 0, 0, 0])
 
     # ---- the collective part (same on both entry points)
     def _exchange(self, n: int, sharded: bool, bounds, local_fn, whole_fn, out=None) -> torch.Tensor:

@@ -102,12 +102,15 @@ class MI355XRanker:
     PRESCORE_WINDOW_S = 3e-4     # prescore: arrivals closer together than the host time of one launch share a forward
     PRESCORE_BURST_S = 5e-3      # prescore: launches inside this window count as one burst (growing batches)
     PRESCORE_GRAPH_BUCKET = 64   # prescore: one captured graph per this many tokens of (prompt + >= 1 dummy token)
+    PRESCORE_ORPHAN_S = 30.0     # prescore: a finished batch nobody collected for this long (aborted requests) is dropped
+    PRESCORE_MAX_STAGERS = 16    # prescore: pinned staging sets kept for reuse (more in flight: allocated, then freed)
 
     def __init__(self, scorer: HipOPTScorer, schedule_type: str = "opt", max_length: int = 2048,
                  tokenize: Optional[Callable[[str], List[int]]] = None, mtype: str = "rank",
                  xpt_distribution=None, group=None, min_requests_to_shard: Optional[int] = None,
                  min_tokens_to_shard: Optional[int] = None, collective_timeout_s: Optional[float] = None,
-                 mirror_host: bool = False, prescore: bool = False, prescore_graphs: bool = True):
+                 mirror_host: bool = False, prescore: bool = False, prescore_graphs: bool = True,
+                 driver_rank: Optional[int] = None):
         """
         scorer      the HBM-resident predictor
         schedule_type  the reference's schedule string (``opt-...-starv<S>-period<P>``; an ``xpt{path}...``
@@ -123,6 +126,12 @@ class MI355XRanker:
                     ranks of the group (every rank must make the same call, SPMD) with one all-gather of the
                     scores (RCCL over xGMI); the reference instead runs the predictor tensor-parallel over the
                     backbone's TP group (llm_engine.py:237).  None: this GPU scores alone.
+        driver_rank  None: SPMD - every rank of ``group`` makes the same ``obtain_aux_scores`` call with the same batch.
+                    An int: the vllm-ltr engine's shape - only THAT rank of the group has a scheduler and calls
+                    ``obtain_aux_scores``; the other ranks build the same ranker and sit in :meth:`serve` (what
+                    ``execute_aux_method`` is to the reference's workers, worker_base.py:151-166): the driver sends each
+                    worker its shard of the batch (header broadcast + one scatter, distributed.py), all score, one
+                    all-gather; calls below the shard threshold involve no worker.  :meth:`close` ends the workers' loops.
         min_tokens_to_shard  shard a scoring call only when it holds more tokens than this (default: one pass of one GPU,
                     196,608 - north_star: "only when the queue exceeds a single GPU's batch"); ``min_requests_to_shard``
                     replaces it with a rule on the request count.  ``collective_timeout_s`` bounds every collective of a
@@ -159,7 +168,9 @@ class MI355XRanker:
             from .distributed import ShardedScorer
             self._sharded = ShardedScorer(self.scorer, self.device, group=group,
                                           min_requests_to_shard=min_requests_to_shard,
-                                          min_tokens_to_shard=min_tokens_to_shard, timeout_s=collective_timeout_s)
+                                          min_tokens_to_shard=min_tokens_to_shard, timeout_s=collective_timeout_s,
+                                          driver_rank=0 if driver_rank is None else driver_rank)
+        self.driver_rank = driver_rank if group is not None else None
         starv, period = (self.st.starv, self.st.period) if self.st.policy == "opt" else (-1, 0)
         self.queue = DeviceQueue(self.device, starv=starv, period=period, capacity=1 << 13)
         # the slot number lives on the request object under a per-ranker attribute name (two rankers - e.g. in a
@@ -181,9 +192,10 @@ class MI355XRanker:
         self._score_ms: collections.deque = collections.deque(maxlen=1000)
         self._rank_ms: collections.deque = collections.deque(maxlen=1000)
         # ---- asynchronous scoring at arrival (prescore=True)
-        if prescore and group is not None:
-            raise ValueError("prescore=True does not combine with group=: the ranks of a sharded call must make the same "
-                             "collective calls, and arrivals are not synchronised across ranks")
+        if prescore and group is not None and driver_rank is None:
+            raise ValueError("prescore=True does not combine with an SPMD group=: the ranks of a sharded call must make the "
+                             "same collective calls, and arrivals are not synchronised across ranks (with driver_rank= the "
+                             "arrival-time forwards are the driver's own and the combination is fine)")
         self.prescore = bool(prescore)
         self.prescore_graphs = bool(prescore_graphs)
         self._pre_static: Optional[dict] = None
@@ -195,7 +207,7 @@ class MI355XRanker:
         self._pre_up = _PinnedI32(self.device, 1 << 8) if self.prescore else None
         self._pre_recent: collections.deque = collections.deque()     # issue times of the launches of the last PRESCORE_BURST_S
         self.stats.update(prescore_launches=0, prescore_graph_replays=0, prescored_requests=0, prescore_wait_seconds=0.0,
-                          arrival_hook_seconds=0.0)
+                          arrival_hook_seconds=0.0, prescore_orphans=0, range_fallbacks=0)
 
     def __del__(self):
         # the prescore scratch this ranker parked on the (possibly shared) scorer
@@ -329,14 +341,13 @@ class MI355XRanker:
             ev.record(self._pre_stream)
         if graph is not None:
             self.stats["prescore_graph_replays"] += 1
-        rec = dict(reqs=batch, scores_host=scores_host, event=ev, stager=stager, left=len(batch))
+        rec = dict(reqs=batch, scores_host=scores_host, event=ev, stager=stager, left=len(batch), t=now)
         for i, sg in enumerate(batch):
             sg._ltr_pre = (rec, i)
         self._pre_inflight.append(rec)
         self.stats["prescore_launches"] += 1
-        # batches nobody collected (aborted requests): keep the list bounded
-        while len(self._pre_inflight) > 256 and self._pre_inflight[0]["event"].query():
-            self._prescore_retire(self._pre_inflight.popleft())
+        if len(self._pre_inflight) > 8:
+            self._prescore_sweep(now)
 
     def _prescore_graph(self, ids: np.ndarray, stager) -> Optional["torch.cuda.CUDAGraph"]:
         """A one-request forward as a captured graph (the common prescore launch: a lone arrival).  The request is padded
@@ -404,7 +415,39 @@ class MI355XRanker:
         for sg in rec["reqs"]:
             if getattr(sg, "_ltr_pre", None) is not None and sg._ltr_pre[0] is rec:
                 sg._ltr_pre = None
-        self._pre_free_stagers.append(rec["stager"])
+        rec["reqs"] = ()                                    # (no reference cycle request -> record -> request left behind)
+        if len(self._pre_free_stagers) < self.PRESCORE_MAX_STAGERS:
+            self._pre_free_stagers.append(rec["stager"])
+        rec["stager"] = None
+
+    def _prescore_sweep(self, now: Optional[float] = None) -> None:
+        """Retire every launched batch that is done with - all its requests collected or aborted - WHEREVER it sits in the
+        list (one aborted request at the head must not keep every later batch and its pinned staging alive), and batches
+        whose forward finished ``PRESCORE_ORPHAN_S`` ago without anybody asking for the scores (requests aborted without
+        :meth:`abort_request`): should such a request still show up in a scheduler step, the step scores it itself."""
+        now = time.perf_counter() if now is None else now
+        keep = collections.deque()
+        for rec in self._pre_inflight:
+            if rec["left"] <= 0 and rec["event"].query():
+                self._prescore_retire(rec)
+            elif now - rec["t"] > self.PRESCORE_ORPHAN_S and rec["event"].query():
+                self.stats["prescore_orphans"] += rec["left"]
+                self._prescore_retire(rec)
+            else:
+                keep.append(rec)
+        self._pre_inflight = keep
+
+    def abort_request(self, sg) -> None:
+        """Optional hook where the engine aborts a request (``Scheduler.abort_seq_group``, scheduler.py:378-409): forget the
+        score started for it at arrival.  Without it the record is dropped by age (``PRESCORE_ORPHAN_S``)."""
+        if not self.prescore:
+            return
+        pre = getattr(sg, "_ltr_pre", None)
+        if pre is not None:
+            pre[0]["left"] -= 1
+            sg._ltr_pre = None
+        if self._pre_pending:
+            self._pre_pending = [g for g in self._pre_pending if g is not sg]
 
     def obtain_aux_scores(self, seq_groups) -> List[float]:
         seq_groups = list(seq_groups)
@@ -419,21 +462,18 @@ class MI355XRanker:
             todo = self._collect_prescored(seq_groups, out)
         if todo:
             batch = [seq_groups[i] for i in todo]
-            arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in batch]
-            ids_dev, cu_dev, cu_host = self._stager.stage(arrays)          # pinned pack + async H2D
-            if self._sharded is not None:
-                scores_dev = self._sharded.score_device(ids_dev, cu_dev, cu_host)
-            else:
-                scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host)
-            # the scores stay on the device in the requests' slots; the host copy is only for the
-            # reference-visible ``aux_model_score`` attribute
-            self._assign_slots(batch, being_scored=True)
-            slots = torch.from_numpy(np.fromiter(map(self._get_slot, batch), np.int64, len(batch))).to(self.device)
-            self.queue.set_scores(slots, scores_dev)
-            scores = self._stager.fetch_scores(scores_dev)
-            for i, v in zip(todo, scores.tolist()):            # opt.py:408 .tolist()
+            for i, v in zip(todo, self._score_now(batch)):
                 out[i] = v
-        self._check_status()                               # out-of-vocabulary ids raise, like F.embedding
+        try:
+            self._check_status()                           # out-of-vocabulary ids raise, like F.embedding
+        except _lib.LtrError as e:
+            if e.code != _lib.LTR_E_RANGE:
+                raise
+            # The residual stream of this checkpoint left the fp16 range of the LayerNorm-fold operand somewhere in this
+            # call (or in a forward started at arrival): its scores are invalid.  The reference would carry on (its fp16
+            # path overflows only at |x| > 65504) and an exception here ends the engine (llm_engine.py:569): re-score the
+            # whole batch on a handle that feeds the GEMMs the bounded LayerNorm output, keep using that handle.
+            out = self._rescore_unfolded(seq_groups)
         for sg, s in zip(seq_groups, out):
             sg.set_aux_model_score(s)                      # aux_llm_engine.py:408-410
         dt = time.perf_counter() - t0
@@ -442,6 +482,61 @@ class MI355XRanker:
         self.stats["score_seconds"] += dt
         self._score_ms.append(dt * 1e3)
         return out
+
+    def _score_now(self, batch) -> List[float]:
+        """One forward over ``batch`` (this GPU alone, or sharded over the group): scores into the requests' device slots,
+        host values returned."""
+        arrays = [cached_token_ids(sg, self.tokenize, self.max_length) for sg in batch]
+        ids_dev, cu_dev, cu_host = self._stager.stage(arrays)          # pinned pack + async H2D
+        if self._sharded is not None and self.driver_rank is not None:
+            scores_dev = self._sharded.score_from_driver(ids_dev, cu_dev, cu_host)     # the workers are in serve()
+        elif self._sharded is not None:
+            scores_dev = self._sharded.score_device(ids_dev, cu_dev, cu_host)
+        else:
+            scores_dev = self.scorer.score_device(ids_dev, cu_dev, cu_host)
+        # the scores stay on the device in the requests' slots; the host copy is only for the
+        # reference-visible ``aux_model_score`` attribute
+        self._assign_slots(batch, being_scored=True)
+        slots = torch.from_numpy(np.fromiter(map(self._get_slot, batch), np.int64, len(batch))).to(self.device)
+        self.queue.set_scores(slots, scores_dev)
+        return self._stager.fetch_scores(scores_dev).tolist()            # opt.py:408 .tolist()
+
+    def _use_unfolded_twin(self) -> None:
+        """Switch this ranker (and its sharded wrapper) to a handle created with ``LTR_F_NO_LN_FOLD`` - for the rest of the
+        process: a checkpoint that overflowed the folded operand once will do so again."""
+        if not getattr(self.scorer, "ln_fold", False):
+            return
+        twin = self.scorer.unfolded_twin()
+        self.scorer = twin
+        if self._sharded is not None:
+            self._sharded.scorer = twin
+        if self._pre_static is not None:                    # the captured graphs replay the folded handle's launches
+            self._pre_stream.synchronize()
+            self._pre_static = None
+
+    def _rescore_unfolded(self, seq_groups) -> List[float]:
+        if not getattr(self.scorer, "ln_fold", False):
+            raise _lib.LtrError("ltr_score: LTR_E_RANGE on a handle that does not fold its LayerNorms", _lib.LTR_E_RANGE)
+        self._use_unfolded_twin()
+        if self._sharded is not None:
+            self._sharded.unfolded = True                   # driver mode: the next header tells the workers to switch too
+        self.stats["range_fallbacks"] += 1
+        out = self._score_now(seq_groups)
+        self._check_status()                                # (a second failure - e.g. a bad token id - raises)
+        return out
+
+    # ---- driver / workers mode -------------------------------------------------------------------------------------
+    def serve(self) -> int:
+        """Worker ranks of ``MI355XRanker(group=, driver_rank=)``: score the shards the driver sends until it closes.
+        Returns the number of sharded calls served."""
+        if self._sharded is None or self.driver_rank is None or self._sharded.rank == self.driver_rank:
+            raise RuntimeError("serve() is for the non-driver ranks of MI355XRanker(group=, driver_rank=)")
+        return self._sharded.serve()
+
+    def close(self) -> None:
+        """Driver: end the workers' :meth:`serve` loops (no-op otherwise)."""
+        if self._sharded is not None and self.driver_rank is not None and self._sharded.rank == self.driver_rank:
+            self._sharded.stop_workers()
 
     def _collect_prescored(self, seq_groups, out) -> list:
         """Scores of the requests whose forward was started at arrival: into their device slots (the ordering reads them
@@ -482,9 +577,8 @@ class MI355XRanker:
             up = self._pre_up.upload(2 * n_pre)
             self.queue.set_scores(up[:n_pre].to(torch.int64), up[n_pre:].view(torch.float32))
             self.stats["prescored_requests"] += n_pre
-        # retire finished batches from the head of the list (their staging buffers go back to the pool)
-        while self._pre_inflight and self._pre_inflight[0]["left"] <= 0:
-            self._prescore_retire(self._pre_inflight.popleft())
+        # retire the batches that are done with (their staging buffers go back to the pool)
+        self._prescore_sweep()
         return todo
 
     def metrics(self) -> dict:
@@ -503,10 +597,11 @@ class MI355XRanker:
                               mean_ms_per_call=st["rank_seconds"] * 1e3 / st["rank_calls"] if st["rank_calls"] else None,
                               last=pct(self._rank_ms)),
                     live_slots=self._live_slots, queue_length=self._n_members,
-                    sharded=self._sharded is not None,
+                    sharded=self._sharded is not None, range_fallbacks=st["range_fallbacks"],
                     two_lane_calls=self.scorer.lane_calls() if hasattr(self.scorer, "lane_calls") else 0,
                     prescore=dict(enabled=self.prescore, launches=st["prescore_launches"],
                                   graph_replays=st["prescore_graph_replays"], requests=st["prescored_requests"],
+                                  orphans=st["prescore_orphans"], inflight=len(self._pre_inflight),
                                   wait_ms_total=st["prescore_wait_seconds"] * 1e3,
                                   arrival_hook_ms_total=st["arrival_hook_seconds"] * 1e3))
 
@@ -521,14 +616,15 @@ class MI355XRanker:
             self.scorer.check_status()
         except _lib.LtrError as e:
             err = e
-        if self._sharded is not None:
+        if self._sharded is not None and (self.driver_rank is None or self._sharded.last_call_collective):
+            self._sharded.last_call_collective = False      # (driver mode: one agreement per call the workers took part in)
             mine = 0 if err is None else (2 if err.code == _lib.LTR_E_RANGE else 1)
             code = self._sharded.agree_status(mine)
             if code and err is None:
                 if code == 2:
                     err = _lib.LtrError("ltr_score: on another rank of the group the residual stream left the fp16 range of "
-                                        "the LayerNorm-fold operand; the scores of this call are invalid on every rank - "
-                                        "create the handles with LTR_NO_LN_FOLD=1 for this checkpoint", _lib.LTR_E_RANGE)
+                                        "the LayerNorm-fold operand; the scores of this call are invalid on every rank "
+                                        "(every rank re-scores on its unfolded twin handle)", _lib.LTR_E_RANGE)
                 else:
                     err = _lib.LtrError("ltr_score: another rank of the group met a token id outside the predictor's "
                                         "vocabulary (F.embedding raises on it, vocab_parallel_embedding.py:95-106); the "
