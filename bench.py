@@ -135,8 +135,20 @@ def cpu_baseline(spec, ckpt, ids, cu, starv, period, budget_s: float = 12.0):
     order = rs.opt_order(reqs, starv, period)
     rs.age_update(reqs, order[:256])
     t_rank = time.perf_counter() - t
+    # what more threads give: the same 8-request sample at 32 / 64 / 128 threads (~1 s each)
+    sweep = {}
+    for th in (32, 64, 128):
+        if th > avail:
+            break
+        torch.set_num_threads(th)
+        orc.score_packed(ids[:cu[2]], cu[:3])
+        t = time.perf_counter()
+        orc.score_packed(ids[:cu[n0]], cu[:n0 + 1])
+        sweep[str(th)] = n0 / (time.perf_counter() - t)
+    torch.set_num_threads(cores)
     return dict(value=n / (t_score + t_rank), unit="requests/s", cores=cores, threads=cores, host_cores=os.cpu_count(),
                 host_cores_usable=avail, kind="port",
+                threads_sweep=dict(requests_per_s=sweep, sample=f"first {n0} requests ({int(cu[n0])} tokens), one packed forward"),
                 sample=f"first {n} requests of the same queue ({int(cu[n])} tokens): oracle fp32 torch "
                        f"forward packed<=2048 tok ({t_score:.2f}s) + literal Python rank/age ({t_rank*1e3:.2f}ms)")
 
@@ -145,14 +157,18 @@ class ColdCall:
     """One global queue of ``n_total`` requests, resident on every rank, and its cold ranker call."""
 
     def __init__(self, spec, scorer, dev, dist, world, rank, n_total, profile, min_shard_tokens, starv, period, seed=0,
-                 timeout_s=None):
+                 timeout_s=None, driver_mode=False):
         from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
         from vllm_ltr_amd.rank import DeviceQueue
         self.scorer, self.dev, self.dist, self.world, self.rank, self.n_total = scorer, dev, dist, world, rank, n_total
         self.ids, self.cu, self.lens = synthetic_queue(spec, n_total, seed=seed, profile=profile)
-        self.ids_d = torch.from_numpy(self.ids).to(dev)
-        self.cu_d = torch.from_numpy(self.cu).to(dev)
-        self.sharded = ShardedScorer(scorer, dev, min_tokens_to_shard=min_shard_tokens, timeout_s=timeout_s) if world > 1 else None
+        # --driver-broadcast: only rank 0 (the rank that would own the scheduler) holds the queue on its device; the other
+        # ranks receive their shard INSIDE every step (header broadcast + one scatter, distributed.py) and never see the rest
+        self.driver_mode = bool(driver_mode and world > 1)
+        self.passive = self.driver_mode and rank != 0
+        self.ids_d = None if self.passive else torch.from_numpy(self.ids).to(dev)
+        self.cu_d = None if self.passive else torch.from_numpy(self.cu).to(dev)
+        self.sharded = ShardedScorer(scorer, dev, min_tokens_to_shard=min_shard_tokens, timeout_s=timeout_s, driver_rank=0) if world > 1 else None
         self.is_sharded = bool(self.sharded is not None and self.sharded.shards(n_total, int(self.cu[-1])))
         self.bounds = shard_bounds(self.cu, world) if self.is_sharded else [(0, n_total)] + [(n_total, n_total)] * (world - 1)
         self.r0, self.r1 = self.bounds[rank]
@@ -169,6 +185,16 @@ class ColdCall:
 
     def step(self):
         out = self.queue._score[:self.n_total]
+        if self.driver_mode:
+            if self.passive:
+                if self.is_sharded:                     # (an unsharded call never reaches a worker)
+                    self.sharded.serve_once()
+                return
+            self.sharded.score_from_driver(self.ids_d, self.cu_d, self.cu, out=out)
+            if self.sharded.last_call_collective:
+                self.sharded.agree_status(0)            # the status agreement every collective call ends with
+            self.rank_part()
+            return
         if self.sharded is not None:
             # the one exchange step of the path: RCCL all-gather of f32 score shards over xGMI, compacted straight
             # into the queue's score slots
@@ -287,7 +313,14 @@ def main():
                          "than one pass of one GPU (north_star: 'only when the queue exceeds a single GPU's batch')")
     ap.add_argument("--collective-timeout", type=float, default=600.0,
                     help="seconds a rank waits for its peers in a collective before it raises (a dead peer must not hang the node)")
-    ap.add_argument("--weight-dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--weight-dtype", default="f16", choices=["f16", "f32", "f16-1pass"],
+                    help="f16 (default): fp16 weights x (hi+lo) fp16 activations - the 1e-4 contract, the headline; f32: exact f32 "
+                         "MFMA; f16-1pass: ONE fp16 MFMA pass per product = the reference's own fp16 GPU arithmetic (~2e-3 from "
+                         "the fp32 scores): a second, separately labelled number, never the headline")
+    ap.add_argument("--driver-broadcast", action="store_true",
+                    help="N > 1: only rank 0 holds the queue (the rank that owns the scheduler in a vllm-ltr engine); every "
+                         "timed step includes the distribution of the inputs to the other ranks (header + per-rank scatter)")
+    ap.add_argument("--no-scale-points", action="store_true", help="skip the 1k / 4k / 16k points of north_star's table (scale_table)")
     ap.add_argument("--chunk-tokens", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unfused", action="store_true",
@@ -376,7 +409,9 @@ def main():
     n_total = args.queue_total if strong else args.queue * world
     n_local = n_total // world if strong else args.queue
     mk = lambda n: ColdCall(spec, scorer, dev, dist, world, rank, n, args.profile, args.min_shard_tokens, args.starv, args.period,
-                            timeout_s=args.collective_timeout)
+                            timeout_s=args.collective_timeout, driver_mode=args.driver_broadcast)
+    f16 = args.weight_dtype in ("f16", "f16-1pass")        # both run the fp16-weight kernels
+    one_pass = args.weight_dtype == "f16-1pass"
 
     if args.sweep:
         # north_star: "ranker calls/sec on synthetic 1k-64k-request queues reported at 1/2/4/8 GPUs as absolute numbers and as
@@ -412,15 +447,10 @@ def main():
     call.barrier()
     # The GEMM launches of the default build also carry the LayerNorm work (LayerNorm fold, ltr_gemm.hip), so their
     # FLOP rate is not comparable with a plain GEMM's.  For the record, time the same call once more on a second handle
-    # with the fold off (LTR_NO_LN_FOLD is read at ltr_create): `roofline.unfused` below.  Outside the timed region.
+    # with the fold off (LTR_F_NO_LN_FOLD at ltr_create): `roofline.unfused` below.  Outside the timed region.
     unfused = None
-    if rank == 0 and args.weight_dtype == "f16" and not args.no_unfused \
-            and os.environ.get("LTR_NO_LN_FOLD") != "1":
-        os.environ["LTR_NO_LN_FOLD"] = "1"
-        try:
-            sc2 = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens)
-        finally:
-            del os.environ["LTR_NO_LN_FOLD"]
+    if rank == 0 and f16 and not args.no_unfused and os.environ.get("LTR_NO_LN_FOLD") != "1":
+        sc2 = HipOPTScorer(spec, ckpt, str(dev), args.weight_dtype, chunk_tokens=args.chunk_tokens, ln_fold=False)
         tmp = torch.empty(my_r1 - my_r0, dtype=torch.float32, device=dev)
         cu_loc = np.ascontiguousarray(cu[my_r0:my_r1 + 1] - cu[my_r0]).astype(np.int32)
         ids_loc, cu_loc_d = call.ids_d[int(cu[my_r0]):int(cu[my_r1])], torch.from_numpy(cu_loc).to(dev)
@@ -456,7 +486,7 @@ def main():
     # steady calls with k new requests: score the first k of the local queue on THIS GPU, then
     # promote/demote + sort + budget prefix + aging over the whole queue - what a scheduler step with k arrivals pays
     steady = {}
-    for k_new in [int(x) for x in args.steady_new.split(",") if x.strip() and int(x) > 0]:
+    for k_new in [] if call.passive else [int(x) for x in args.steady_new.split(",") if x.strip() and int(x) > 0]:
         k_new = min(k_new, n_total)
         cu_k = np.ascontiguousarray(cu[:k_new + 1])
         ids_k, cu_k_d = call.ids_d[:int(cu_k[-1])], call.cu_d[:k_new + 1]
@@ -480,6 +510,22 @@ def main():
         strong_pt = dict(queue_total=65536, tokens_total=int(c64.cu[-1]), n_gpus=world, ms_per_call=el / 2 * 1e3,
                          requests_per_s=65536 * 2 / el, scaling="strong", tokens_shard=c64.tokens_shard)
         c64.release(); del c64
+
+    # ---- three more points of north_star's table (fixed queues of 1k / 4k / 16k requests at this N; the 8k point is the
+    # headline, the 64k point `strong_scaling`): calls/s at five queue sizes in the driver's own record
+    scale_pts = None
+    if not args.no_scale_points and not strong and not args.sweep:
+        if strong_pt is None:
+            call.release()
+        scale_pts = []
+        for n_q in (1024, 4096, 16384):
+            c = mk(n_q)
+            el, _ = c.timed(2, 1)
+            lin_q, att_q = model_flops(spec, c.lens)
+            scale_pts.append(dict(queue_total=n_q, tokens_total=int(c.cu[-1]), ms_per_call=el / 2 * 1e3, calls_per_s=2 / el,
+                                  requests_per_s=n_q * 2 / el, sharded=c.is_sharded,
+                                  mfma_frac=(lin_q + att_q) / (el / 2) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world)))
+            c.release(); del c
 
     # ---- class-mode head at the reference's largest bucket count (train/train.sh: 8,192 labels; opt.py:389-397): the
     # head of an 8,192-request call = final LayerNorm of the last-token rows + [8192, De] x [8192, De]^T logits on the
@@ -527,7 +573,7 @@ def main():
             if "embed" in kernels:
                 # SURVEY.md 8d counts 4616 B per token for the gather (a 2-byte activation row out); this kernel writes an
                 # f32 residual row (6152 B, the `gbs` above).  The fraction on SURVEY's own bytes:
-                w = 2.0 if args.weight_dtype == "f16" else 4.0
+                w = 2.0 if f16 else 4.0
                 survey_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * w
                 ours_b = 8.0 + (spec.word_embed_proj_dim + spec.hidden_size) * w + spec.hidden_size * 4.0
                 kernels["embed"]["frac_hbm_survey_bytes"] = kernels["embed"]["frac_hbm"] * survey_b / ours_b
@@ -552,12 +598,12 @@ def main():
             except Exception:
                 pass
             avg_launch_s = gemm["ms"] / max(gemm["launches"], 1) * 1e-3
-            peak = PEAK_F16_MFMA_TFLOPS if args.weight_dtype == "f16" else 157.3
+            peak = PEAK_F16_MFMA_TFLOPS if f16 else 157.3
             launches_per_step = gemm["launches"] // max(args.steps, 1)
             passes = max(1, -(-int(cu[my_r1] - cu[my_r0]) // 196608))
             comp = compulsory_bytes(spec, int(cu[my_r1] - cu[my_r0]), passes) if args.weight_dtype == "f16" else None
             n_pass = 2 if args.weight_dtype == "f16" else 1              # fp16 MFMA passes per product (lo, hi)
-            roof = {"bound": "mfma", "kernel": "gemm_f16s_kernel" if args.weight_dtype == "f16" else "gemm_f32_kernel",
+            roof = {"bound": "mfma", "kernel": "gemm_f16s_kernel" if f16 else "gemm_f32_kernel",
                     "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
                     # `frac` is ALGORITHMIC (2 M N K per product).  The split path issues every product twice (lo x W, hi x W):
                     # the matrix cores run at hw_frac of their fp16 peak
@@ -565,7 +611,7 @@ def main():
                     # the same MFMA instruction stream alone, fed from registers with real operands, under the 1.4 kW package
                     # cap (1.98 PFLOP/s of 16x16x32 fp16 MFMA at the throttled clock, profiles/r01_power_probe.txt): the time the
                     # GEMMs of one step would take if the operand stream, LDS reads and epilogues cost nothing
-                    "mfma_only_floor_ms": gemm["work"] / max(args.steps, 1) * n_pass / 1.98e15 * 1e3 if args.weight_dtype == "f16" else None,
+                    "mfma_only_floor_ms": gemm["work"] / max(args.steps, 1) * n_pass / 1.98e15 * 1e3 if f16 else None,
                     "traffic": traffic,
                     # bytes the GEMM launches of one call MUST move in this layout (compulsory_bytes()) against
                     # what the PMC passes counted at the fabric for the same launches
@@ -587,7 +633,7 @@ def main():
                     "measured": "second pass of the same K steps with HIP events around every launch (profiler off in the timed region)",
                     "note": "the GEMM launches also carry the LayerNorm work of the layer (LayerNorm fold: operand + row "
                             "statistics in the producer epilogue, normalisation in the consumer epilogue); "
-                            "`unfused` = the same forward with separate LayerNorm launches (LTR_NO_LN_FOLD=1)",
+                            "`unfused` = the same forward with separate LayerNorm launches (LTR_F_NO_LN_FOLD)",
                     "unfused": unfused,
                     # MFMA pipe utilisation / L2 hit rate of the kernel from the last PMC passes (profiles/gemm_pmc.json)
                     "pmc": pmc}
@@ -612,7 +658,7 @@ def main():
             # steady call with k new requests: score k + re-rank the whole queue (one GPU; SURVEY 8d "steady")
             "p50_steady_new_latency_ms": steady or None,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if args.weight_dtype == "f16" else "f32",
+            "dtype": "f16 weights x (hi+lo) f16 activations, f32 accumulate" if f16 else "f32",
             "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths, random token ids)",
             "config": {"workload": (f"OPT-{args.model} predictor, fixed {n_total}-request synthetic queue ({args.profile} length "
                                     f"profile), cold ranker call" if strong else
@@ -626,8 +672,18 @@ def main():
             "roofline": roof,
             "kernels": kernels,
             "strong_scaling": strong_pt,
+            # north_star: "ranker calls/sec on synthetic 1k-64k-request queues": cold calls on FIXED queues at this N
+            # (with the headline = the 8k point and strong_scaling = the 64k point: five queue sizes)
+            "scale_table": scale_pts,
             "model_tflop_per_step": (lin + att) / 1e12,
+            "input_distribution": ("driver-broadcast: only rank 0 holds the queue; header broadcast + one per-rank scatter of "
+                                   "(cu_seqlens slice, token ids) inside every timed step" if args.driver_broadcast and world > 1
+                                   else "resident: every rank holds the whole queue before the timed region (SPMD)"),
         }
+        if one_pass:
+            out["metric"] = ("requests ranked/sec, ONE fp16 MFMA pass per product (the reference's fp16 GPU arithmetic, ~2e-3 from "
+                             "the fp32 predictor: NOT the 1e-4 headline metric)")
+            out["dtype"] = "f16 weights x f16 activations (one MFMA pass), f32 accumulate"
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(spec, ckpt, ids, cu, args.starv, args.period)
         print(json.dumps(out))

@@ -64,8 +64,10 @@ typedef struct ltr_model_desc {
  *  LTR_F_ONE_PASS    F16 mode with ONE fp16 MFMA pass per product: activations rounded to fp16 (the `lo` plane is neither
  *                    loaded nor multiplied), f32 accumulate - the arithmetic of the reference's own GPU path (fp16 model,
  *                    vllm/config.py:906-943; train/trainer.py:213-216).  Scores move by ~2e-3 against the fp32 predictor:
- *                    OUTSIDE the 1e-4 contract of the default mode; opt-in, reported as its own number by bench.py. */
-enum { LTR_F_NO_LN_FOLD = 1, LTR_F_NO_LANES = 2, LTR_F_ONE_PASS = 4 };
+ *                    OUTSIDE the 1e-4 contract of the default mode; opt-in, reported as its own number by bench.py.
+ *  LTR_F_LANES_UNPROBED  keep the first lane-stream candidate without the overlap probe (tests of the two-lane
+ *                    arithmetic, which does not depend on whether the halves overlap; lab). */
+enum { LTR_F_NO_LN_FOLD = 1, LTR_F_NO_LANES = 2, LTR_F_ONE_PASS = 4, LTR_F_LANES_UNPROBED = 8 };
 
 /* Order of the device pointers handed to ltr_create (HF tensor names in comments).
  * Matrices / tables are row-major [out, in] in `weight_dtype`; biases, LayerNorm
@@ -133,7 +135,7 @@ int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens);
 int64_t ltr_lane_calls(ltr_handle h);
 /* Whether the two lanes really run side by side is a property of the PROCESS: the HIP runtime multiplexes all streams of a
  * process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a lane stream that lands on the hardware queue of
- * the caller's stream runs its half AFTER the caller's, slower than one lane.  ltr_create therefore probes (two ~20 us spin
+ * the caller's stream runs its half AFTER the caller's, slower than one lane.  ltr_create therefore probes (two 150 us spin
  * kernels, one per stream, fork / join) and keeps a lane stream only if it overlaps with `stream`; candidates are tried at
  * normal, then at high priority (a queue of its own class); when none overlaps the handle runs on one lane.  A call made
  * while `stream` is being captured into a graph also runs on one lane (the split is taken from the HOST copy of cu_seqlens,

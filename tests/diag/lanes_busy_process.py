@@ -2,13 +2,14 @@
 a serving engine - dozens of handles and streams alive - and not only in bench.py's?  (k = 64 took 3.93 ms
 inside the driver's pytest process, 2.91 in its bench, 2.97 on ONE lane.)
 
-    [LTR_LANE_PROBE=0] python tests/diag/lanes_busy_process.py
+    python tests/diag/lanes_busy_process.py
 
-Stage A: a fresh process.  Stage B: after 32 more handles (each owns a lane stream) and 32 torch streams that have run work.
-In each stage a NEW pair of scorers (lanes on / off) is created - what test #185 did - and timed alternately at k = 16 / 64
-arrivals (+ re-rank of the 8k queue); `ltr_lane_probe` reports how many candidate streams ltr_create went through and the
-fork / join spin measurement (pair ~ solo: concurrent, ~ 2 x solo: the lane stream shares the caller's hardware queue).
-LTR_LANE_PROBE=0 = the round-4 behaviour (first candidate kept unprobed)."""
+Handles are created one after the other - what a test suite or an engine with several predictors does - first in a fresh
+process, then after 32 more handles (each owns a lane stream) and 32 torch streams that have run work.  "unprobed" = the
+round-4 behaviour (the first candidate stream is kept, `LTR_F_LANES_UNPROBED`), "probed" = the default (ltr_create keeps a
+candidate only if a 150-us spin on it overlaps one on the caller's stream).  Per handle: `ltr_lane_probe` (pair ~ solo:
+concurrent, ~ 2 x solo: the lane stream shares the caller's hardware queue) and the k = 16 / 64 steady call (+ re-rank of the
+8k queue) against a one-lane handle, alternately."""
 import os
 import sys
 
@@ -51,23 +52,29 @@ def timed(sc, k, reps=21):
     return ms[len(ms) // 2]
 
 
-def stage(name):
-    two = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
-    one = HipOPTScorer(spec, ckpt, "cuda:0", "f16", lanes=False)
+def stage(name, lanes=True):
+    two = HipOPTScorer(spec, ckpt, "cuda:0", "f16", lanes=lanes)
     tries, solo, pair = two.lane_probe()
-    print(f"[{name}] lane stream: {tries} candidate(s) tried; spin solo {solo:.1f} us, pair {pair:.1f} us "
-          f"({'concurrent' if tries and pair < 1.6 * solo else ('no lane stream' if not tries else 'ALIASED: serial')})")
-    for k in (16, 64, 256):
+    state = "no lane stream" if not tries else ("concurrent" if pair < 1.6 * solo else "ALIASED: serial")
+    line = f"[{name}] lane stream: {tries} candidate(s) tried; spin solo {solo:.0f} us, pair {pair:.0f} us ({state})"
+    for k in (16, 64):
         a = [timed(one, k), timed(two, k), timed(one, k), timed(two, k)]
         before = two.lane_calls()
         timed(two, k, reps=3)
-        used = two.lane_calls() > before
-        print(f"[{name}] k = {k:3d}: one lane {a[0]:.3f} / {a[2]:.3f} ms, lanes handle {a[1]:.3f} / {a[3]:.3f} ms "
-              f"({(min(a[1], a[3]) / min(a[0], a[2]) - 1) * 100:+.1f} %; two lanes in use: {used})")
-    return two, one
+        line += (f"; k = {k}: one lane {min(a[0], a[2]):.3f} ms, this handle {min(a[1], a[3]):.3f} ms "
+                 f"({(min(a[1], a[3]) / min(a[0], a[2]) - 1) * 100:+.1f} %, two lanes used: {two.lane_calls() > before})")
+    print(line, flush=True)
+    return two
 
 
-keep = [stage("A fresh process")]
+one = HipOPTScorer(spec, ckpt, "cuda:0", "f16", lanes=False)
+keep = []
+# Consecutive handles: the runtime maps each new stream to one of its GPU_MAX_HW_QUEUES hardware queues in turn, so one
+# UNPROBED lane stream in every few lands on the queue of the caller's stream; a probed handle never keeps such a stream.
+for i in range(6):
+    keep.append(stage(f"unprobed handle {i}", lanes="unprobed"))
+for i in range(6):
+    keep.append(stage(f"probed handle {i}"))
 tiny = OPTSpec.tiny_pre_ln()
 tck = seeded_checkpoint(tiny, 1)
 for i in range(32):
@@ -78,4 +85,8 @@ for st in streams:
     with torch.cuda.stream(st):
         x.add_(1.0)
 torch.cuda.synchronize()
-keep.append(stage("B +32 handles +32 streams"))
+print("--- after 32 more handles and 32 torch streams that have run work", flush=True)
+for i in range(4):
+    keep.append(stage(f"busy process, unprobed handle {i}", lanes="unprobed"))
+for i in range(4):
+    keep.append(stage(f"busy process, probed handle {i}"))

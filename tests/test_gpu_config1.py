@@ -164,6 +164,33 @@ def test_config1_end_to_end_order_hip_scores_hip_sort(z, scorer, tag):
     assert len(distinct) <= max(1, len(ref) // 100)
 
 
+def test_one_pass_mode_reports_its_distance_from_the_reference(case):
+    """`weight_dtype="f16-1pass"` (LTR_F_ONE_PASS): ONE fp16 MFMA pass per product in the GEMMs - the arithmetic of the
+    reference's own fp16 GPU predictor (vllm/config.py:906-943, trainer.py:213-216), opt-in and OUTSIDE the 1e-4 contract.
+    Against the reference's fp32 scores of the recorded run: the distance is reported (expected ~2e-3), and the cold order
+    a scheduler would see (sort by -score) is compared pair by pair.  Asserted: finite, deterministic, an order of
+    magnitude beyond the default mode's error (so the flag really reached the kernels) and well inside 2e-2."""
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    name, z, two_pass = case
+    spec = two_pass.spec
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", "f16-1pass")
+    ids, cu = z["ids"].astype(np.int64), z["cu_seqlens"]
+    got = sc.score(ids, cu)
+    ref = z["ref_score"]
+    err = np.abs(got - ref)
+    err2 = np.abs(two_pass.score(ids, cu) - ref)
+    order_ref = np.argsort(-ref.astype(np.float64), kind="stable")
+    order_got = np.argsort(-got.astype(np.float64), kind="stable")
+    d = discordant_pairs(order_ref.tolist(), order_got.tolist(), ref)
+    n = len(ref)
+    print(f"{name}: one fp16 pass vs the reference's fp32 predictor over {n} requests: max|d| = {err.max():.3e}, rms "
+          f"{np.sqrt((err ** 2).mean()):.3e} (two passes: max {err2.max():.3e}); cold order: {len(d)} discordant pairs of "
+          f"{n * (n - 1) // 2}, largest reference-score gap among them {max((g for _, _, g in d), default=0.0):.3e}")
+    assert np.isfinite(got).all() and np.array_equal(got, sc.score(ids, cu))
+    assert 10 * err2.max() < err.max() <= 2e-2
+    assert all(g <= 2 * err.max() for _, _, g in d)           # only pairs closer than the arithmetic's own error change places
+
+
 def test_config1_tpt_class_head_end_to_end():
     """Config 1's queue under `tpt` (tests/golden/config1_tpt_class82.npz: the reference's own Scheduler with its class-mode
     predictor, 82 labels): the HIP class head (GEMM + first-maximum argmax) must give the reference's LABEL for every one

@@ -46,7 +46,7 @@ class ModelDesc(C.Structure):
         "pos_rows", "num_labels", "pre_ln", "weight_dtype", "flags")]
 
 
-LTR_F_NO_LN_FOLD, LTR_F_NO_LANES, LTR_F_ONE_PASS = 1, 2, 4
+LTR_F_NO_LN_FOLD, LTR_F_NO_LANES, LTR_F_ONE_PASS, LTR_F_LANES_UNPROBED = 1, 2, 4, 8
 
 
 class HeadDesc(C.Structure):

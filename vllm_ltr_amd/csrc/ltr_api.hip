@@ -74,6 +74,7 @@ struct ltr_model {
   hipEvent_t lane_fork = nullptr, lane_join = nullptr;
   std::mutex lane_mu;
   std::atomic<int64_t> lane_calls{0};
+  bool lane_probe_on = true;       // false: LTR_F_LANES_UNPROBED / LTR_LANE_PROBE=0 (the first candidate is used as it is)
   int lane_tries = 0;              // candidate streams ltr_create probed before it kept one (ltr_lane_probe reports it)
   // caller streams the lane stream has been probed against (guarded by lane_mu): (stream, runs beside it).  ltr_create
   // probes against ITS stream; a call on another stream (a prescore side stream, a worker thread's stream) probes once,
@@ -263,7 +264,12 @@ struct ChunkRun {
         sum_l2(sum_l2_), prune_last(prune_last_), s(s_), d(m_->d), wd(m_->d.weight_dtype), H(m_->d.hidden_size),
         F(m_->d.ffn_dim), De(m_->d.word_embed_proj_dim), Tc(t1_ - t0_), nreq(r1_ - r0_), Mr(t1_ - t0_), hb(ws_.h), ab(ws_.a),
         fb(ws_.f) {}
-  int gemm(const GemmArgs& g) {
+  int gemm(const GemmArgs& g0) {
+    GemmArgs g = g0;
+    if (m->one_pass) {     // LTR_F_ONE_PASS: hi plane only; lo planes that only another GEMM would read are not stored
+      g.one_pass = 1;
+      g.no_lo_out = g.out_slab || g.ln_out.hi ? 1 : 0;     // fc1's ReLU output, the LayerNorm-fold operand (QKV's q|k|v goes to attention: kept)
+    }
     // the dominant kernel (128 x 256 tiles) and the small-batch kernels are timed as separate classes
     ProfScope p(m, wd == LTR_W_F16 && gemm_small_config(g) >= 0 ? LTR_K_GEMM_SMALL : LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
     return launch_gemm(wd, g, s);
@@ -458,8 +464,10 @@ int ChunkRun::layer(const int L) {
 // ---- lane-stream probe.  Two streams of a process run side by side only if the runtime mapped them to different hardware
 // queues (GPU_MAX_HW_QUEUES, 4 by default, shared by every stream of the process); on the same queue the lane's half runs
 // after the caller's - slower than one lane (GPUTEST_r04: k = 64 in 3.93 ms in a process with dozens of handles, 2.91 in
-// bench.py).  A spin of SPIN_TICKS of the 100 MHz wall clock on each stream between fork and join tells the two cases apart.
-constexpr long long SPIN_TICKS = 2000;   // 20 us
+// bench.py; alternating submissions of two streams into ONE hardware queue also pay a dependency per launch).  A spin of
+// SPIN_TICKS of the 100 MHz wall clock on each stream between fork and join tells the two cases apart; it must be long
+// against the fork / join latency itself (~25 us: a 20-us spin read "serial" for streams that do overlap, gpurun r05a).
+constexpr long long SPIN_TICKS = 15000;   // 150 us
 __global__ void lane_spin_kernel(long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
@@ -525,7 +533,7 @@ int check_desc(const ltr_model_desc& d) {
     set_error("ltr_create: bad num_labels/num_layers/vocab/pos_rows");
     return LTR_E_INVAL;
   }
-  if (d.flags & ~(LTR_F_NO_LN_FOLD | LTR_F_NO_LANES | LTR_F_ONE_PASS)) {
+  if (d.flags & ~(LTR_F_NO_LN_FOLD | LTR_F_NO_LANES | LTR_F_ONE_PASS | LTR_F_LANES_UNPROBED)) {
     set_error("ltr_create: unknown flags 0x%x (a caller built against ABI 4 leaves this word uninitialised)", d.flags);
     return LTR_E_INVAL;
   }
@@ -611,7 +619,9 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
     // up to three streams at normal priority, then one at the highest priority (its own hardware-queue class).  Rejected
     // candidates stay alive until the choice is made, so that the next one is mapped to another queue.  LTR_LANE_PROBE=0
     // keeps the first candidate unprobed (the round-4 behaviour; lab).
-    static const bool probe_on = [] { const char* e = getenv("LTR_LANE_PROBE"); return !(e && e[0] == '0'); }();
+    static const bool probe_env = [] { const char* e = getenv("LTR_LANE_PROBE"); return !(e && e[0] == '0'); }();
+    const bool probe_on = probe_env && !(desc->flags & LTR_F_LANES_UNPROBED);
+    m->lane_probe_on = probe_on;
     if (hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming) == hipSuccess &&
         hipEventCreateWithFlags(&m->lane_join, hipEventDisableTiming) == hipSuccess) {
       int lo_pri = 0, hi_pri = 0;
@@ -864,7 +874,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
         const bool labels_gemm = h->head_w != nullptr;
         if (proj) {
           GemmArgs g{};
-          g.a = ws.head_op; g.w = h->proj_out_w; g.M = n; g.N = De; g.K = H; g.a_slab = 1;
+          g.a = ws.head_op; g.w = h->proj_out_w; g.M = n; g.N = De; g.K = H; g.a_slab = 1; g.one_pass = h->one_pass;
           if (labels_gemm) { feat = AOp{ws.head_feat, ws.head_feat + (size_t)n * De * 2}; g.out_split = feat; g.out_slab = 1; }
           else g.out_f32 = (float*)ws.head_feat;
           if ((rc = launch_gemm(wd, g, s))) return rc;
@@ -876,7 +886,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
           for (int rw = 0; rw < n; rw += rb) {
             const int nb = n - rw < rb ? n - rw : rb;
             GemmArgs g{};
-            g.a = feat; g.w = h->head_w; g.N = h->head_lpad; g.K = De; g.a_slab = 1;
+            g.a = feat; g.w = h->head_w; g.N = h->head_lpad; g.K = De; g.a_slab = 1; g.one_pass = h->one_pass;
             g.row0 = rw; g.M = nb; g.ldm = n;
             g.out_f32 = ws.head_logits - (size_t)rw * h->head_lpad;          // (rows are indexed globally: block-local buffer)
             if ((rc = launch_gemm(wd, g, s))) return rc;
@@ -932,8 +942,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     std::unique_lock<std::mutex> lane_lock(h->lane_mu, std::defer_lock);
     if (r_mid > 0 && !lane_lock.try_lock()) r_mid = -1;
     if (r_mid > 0) {                   // does the lane stream run beside THIS caller stream?  (probed once per stream)
-      static const bool probe_on = [] { const char* e = getenv("LTR_LANE_PROBE"); return !(e && e[0] == '0'); }();
-      bool known = !probe_on, ok = true;
+      bool known = !h->lane_probe_on, ok = true;
       for (auto& e : h->lane_seen) if (e.first == s) { known = true; ok = e.second; }
       if (!known) {
         float solo = 0.f, pair = 0.f;

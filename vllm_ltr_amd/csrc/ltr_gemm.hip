@@ -87,6 +87,9 @@ struct Epilogue {
   // Row window (GemmArgs::row0 / ldm): the launch covers rows [row0, M) of tensors that have ldm rows - M is the END of
   // the window, every row index is global; ldm is the pitch of the slab-major images and of the statistics arrays.
   int row0, ldm;
+  // LTR_F_ONE_PASS: one_pass - the small-batch kernels skip the lo MFMA pass (the large-tile kernel has a template
+  // instance without the lo stream); no_lo_out - the lo planes of out_hi / ln_hi's twins are not stored
+  int one_pass, no_lo_out;
 };
 
 // LNS rides on the consumer arithmetic v = (acc - mean c_n) rstd with mean = 0, c_n = 0, rstd = the output scale
@@ -285,7 +288,7 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
 #endif
     {
       epi_store16((__half*)ep.out_hi + os, h);
-      epi_store16((__half*)ep.out_lo + os, l);
+      if (!ep.no_lo_out) epi_store16((__half*)ep.out_lo + os, l);
     }
   }
   if (LNM == LNP) {
@@ -315,7 +318,7 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
     const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
     const size_t oo = slab_off(grow, c0, ldm);
     epi_store16((__half*)ep.ln_hi + oo, &hv);
-    epi_store16((__half*)ep.ln_lo + oo, &lv);
+    if (!ep.no_lo_out) epi_store16((__half*)ep.ln_lo + oo, &lv);
     // (mean, M2) of this 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
     // row, so they are active exactly when this lane is)
     float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
@@ -329,7 +332,9 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
   }
 }
 
-template <int LNM, bool RLN>
+// ONEP (LTR_F_ONE_PASS): the a_lo plane is neither streamed into LDS nor multiplied - one fp16 MFMA pass per product, the
+// arithmetic of the reference's fp16 GPU predictor (the stage layout keeps its lo slot: same LDS addresses, same epilogue).
+template <int LNM, bool RLN, bool ONEP = false>
 __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     const __half* __restrict__ a_hi, const __half* __restrict__ a_lo, const __half* __restrict__ w, int M, int N,
     int K, int lda, int tiles_m, int tiles_n, int gm, Epilogue ep) {
@@ -392,7 +397,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     {
 #endif
       __builtin_amdgcn_global_load_lds((gbl_void*)(ga + ka), (lds_void*)(base + wave * 16 * BK16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
+      if (!ONEP)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(gl + ka), (lds_void*)(base + A_PLANE + wave * 16 * BK16), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -444,7 +450,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
       for (int i = 0; i < 4; ++i) {
         const int row = wr * 64 + i * 16 + frow;
         ah[i] = *reinterpret_cast<const f16x8*>(s_ahi + lds_off_h(row, fk));
-        al[i] = *reinterpret_cast<const f16x8*>(s_alo + lds_off_h(row, fk));
+        if (!ONEP) al[i] = *reinterpret_cast<const f16x8*>(s_alo + lds_off_h(row, fk));
         const int col = wc * 64 + i * 16 + frow;
         bw[i] = *reinterpret_cast<const f16x8*>(s_w + lds_off_h(col, fk));
       }
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #ifndef LTR_EXP_NO_LO    // perf probe (wrong results): what the lo pass costs
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+          if (!ONEP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
 #endif
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
         }
@@ -792,7 +798,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
       for (int i = 0; i < C::TI; ++i)
 #pragma unroll
         for (int j = 0; j < C::TJ; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
+          if (!ep.one_pass) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bw[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bw[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -1126,7 +1132,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, Mend, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
               g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts, g.osc_a, g.osc_b,
-              g.row0, ldm};
+              g.row0, ldm, g.one_pass, g.no_lo_out};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : (g.osc_a ? LNS : LN_NONE));
   if (g.osc_a && (wdtype != LTR_W_F16 || !g.osc_b || g.ln_gamma || g.ln_stats_in || g.rln_stats)) {
     set_error("gemm: scaled operands (osc_a / osc_b) need F16 mode, both scales and no LayerNorm fold");
@@ -1200,7 +1206,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
       epk = Epilogue{};
       // raw partials [parts][window rows][N]; the kernels index rows globally: bias the base by the window's first row
       epk.out_f32 = (float*)g.splitk_ws - (size_t)g.row0 * g.N; epk.M = Mend; epk.N = g.N; epk.a_slab = g.a_slab;
-      epk.row0 = g.row0; epk.ldm = ldm;
+      epk.row0 = g.row0; epk.ldm = ldm; epk.one_pass = g.one_pass;
       lnm_k = LN_NONE; rln_k = false;
     }
     const int kpart = g.K / parts;
@@ -1306,15 +1312,25 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
     }
     if (parts > 1) {                     // the 128 x 256 kernel, split: raw partials, then the epilogue kernel
       grid.y = parts;
-      gemm_f16s_kernel<LN_NONE, false><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N,
-                                                           kpart, g.K, tiles_m, tiles_n, gm, epk);
+      if (g.one_pass)
+        gemm_f16s_kernel<LN_NONE, false, true><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w,
+                                                                   Mend, g.N, kpart, g.K, tiles_m, tiles_n, gm, epk);
+      else
+        gemm_f16s_kernel<LN_NONE, false><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N,
+                                                             kpart, g.K, tiles_m, tiles_n, gm, epk);
       LTR_LAUNCH_CHECK();
       return finish_split();
     }
     grid.y = split;
 #define LTR_BIG_LAUNCH(LN, RL)                                                                                             \
-  gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N, \
-                                                g.K / split, g.K, tiles_m, tiles_n, gm, ep)
+  do {                                                                                                                     \
+    if (g.one_pass)                                                                                                        \
+      gemm_f16s_kernel<LN, RL, true><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend,  \
+                                                          g.N, g.K / split, g.K, tiles_m, tiles_n, gm, ep);                \
+    else                                                                                                                   \
+      gemm_f16s_kernel<LN, RL><<<grid, 512, 0, s>>>((const __half*)g.a.hi, (const __half*)g.a.lo, (const __half*)g.w, Mend, g.N,   \
+                                                    g.K / split, g.K, tiles_m, tiles_n, gm, ep);                           \
+  } while (0)
     if (rln) { if (lnm == LNP) LTR_BIG_LAUNCH(LNP, true); else LTR_BIG_LAUNCH(LN_NONE, true); }
     else if (lnm == LNP) LTR_BIG_LAUNCH(LNP, false);
     else if (lnm == LNC) LTR_BIG_LAUNCH(LNC, false);

@@ -95,6 +95,10 @@ struct GemmArgs {
   // empty, round of 128 x 256 tiles to the small-batch kernels ("tail rows").
   int row0 = 0;
   int ldm = 0;
+  // LTR_F_ONE_PASS (F16 mode): multiply the hi plane of A only (the lo plane is neither streamed nor multiplied);
+  // no_lo_out: do not store the lo planes of out_split / ln_out either (their only reader is another one-pass GEMM)
+  int one_pass = 0;
+  int no_lo_out = 0;
 };
 
 // launchers (each in its own .hip file)

@@ -27,7 +27,8 @@ class HipOPTScorer:
     scores, outside the 1e-4 contract of the default; `LTR_F_ONE_PASS`).
     ln_fold=False: separate LayerNorm launches instead of the GEMM-epilogue fold
     (`LTR_F_NO_LN_FOLD`: the handle a caller falls back to on LTR_E_RANGE).
-    lanes=False: never split a call over two streams (`LTR_F_NO_LANES`).
+    lanes=False: never split a call over two streams (`LTR_F_NO_LANES`); lanes="unprobed": keep the lane stream
+    without the overlap probe (`LTR_F_LANES_UNPROBED`: tests of the two-lane arithmetic).
     """
 
     def __init__(self, spec: OPTSpec, ckpt: Dict[str, np.ndarray], device: str = "cuda:0",
@@ -43,7 +44,7 @@ class HipOPTScorer:
             raise _lib.LtrError(f"weight_dtype {weight_dtype!r}: expected 'f16', 'f32' or 'f16-1pass'")
         self.weight_dtype = weight_dtype
         self.one_pass = weight_dtype == "f16-1pass"
-        self.ln_fold, self.lanes = bool(ln_fold), bool(lanes)
+        self.ln_fold, self.lanes = bool(ln_fold), lanes if lanes == "unprobed" else bool(lanes)
         self._ckpt_ref = ckpt              # (a twin handle without the fold is built from the same arrays: unfolded_twin)
         weight_dtype = "f16" if self.one_pass else weight_dtype
         wt = torch.float16 if weight_dtype == "f16" else torch.float32
@@ -90,7 +91,7 @@ class HipOPTScorer:
                               spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
                               1 if spec.do_layer_norm_before else 0,
                               _lib.LTR_W_F16 if weight_dtype == "f16" else _lib.LTR_W_F32,
-                              (0 if ln_fold else _lib.LTR_F_NO_LN_FOLD) | (0 if lanes else _lib.LTR_F_NO_LANES) |
+                              (0 if ln_fold else _lib.LTR_F_NO_LN_FOLD) | self._lane_flags() |
                               (_lib.LTR_F_ONE_PASS if self.one_pass else 0))
         self._h = C.c_void_p()
         # the library packs the dense-layer weights on THIS stream (ordered after the uploads above, which
@@ -117,6 +118,9 @@ class HipOPTScorer:
         _lib.check(self.lib.ltr_set_chunk_tokens(self._h, int(n)), "ltr_set_chunk_tokens")
         self._ws = None
 
+    def _lane_flags(self) -> int:
+        return _lib.LTR_F_LANES_UNPROBED if self.lanes == "unprobed" else (0 if self.lanes else _lib.LTR_F_NO_LANES)
+
     def unfolded_twin(self) -> "HipOPTScorer":
         """A scorer of the same checkpoint whose GEMMs are fed by separate LayerNorm launches (`LTR_F_NO_LN_FOLD`):
         what `MI355XRanker` re-scores a batch on when this handle reports LTR_E_RANGE.  Shares the weight tensors
@@ -134,8 +138,7 @@ class HipOPTScorer:
                               spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
                               1 if spec.do_layer_norm_before else 0,
                               _lib.LTR_W_F32 if self.weight_dtype == "f32" else _lib.LTR_W_F16,
-                              _lib.LTR_F_NO_LN_FOLD | (0 if self.lanes else _lib.LTR_F_NO_LANES) |
-                              (_lib.LTR_F_ONE_PASS if self.one_pass else 0))
+                              _lib.LTR_F_NO_LN_FOLD | self._lane_flags() | (_lib.LTR_F_ONE_PASS if self.one_pass else 0))
         twin._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), self._stream(), C.byref(twin._h)), "ltr_create")
