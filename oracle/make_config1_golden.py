@@ -32,6 +32,11 @@ scheduled by the reference under ``tpt`` - the class-mode predictor (``OPTSpec.o
 ``float(argmax)``, opt.py:394-395) and the order ``(-score, request_id)`` with STRING request ids (scheduler.py:938-948): 82
 labels over 256 requests, i.e. ties everywhere, broken by ``"10" < "9"``.  Also the reference's top-2 logit gap per request.
 
+``--config outlier`` writes ``tests/golden/outlier_opt125m_64.npz``: the reference's fp32 predictor on a checkpoint with the
+structure of TRAINED OPT weights (``opt_spec.structured_checkpoint``: 5x init scale, two massive embedding channels at
++40 / -55, LayerNorm gains in [0.2, 3]) - 64 requests incl. L = 1, 2 and 1024 - and the order of one cold scheduler step
+(``opt``, no starvation) the reference's own Scheduler returns for those scores.
+
 Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
 """
 from __future__ import annotations
@@ -332,7 +337,44 @@ def main_xpt():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def main_outlier():
+    """OPT-125m shape, structured checkpoint, 64 requests: reference fp32 scores + the reference Scheduler's cold order."""
+    from vllm_ltr_amd.opt_spec import structured_checkpoint
+    mg._init_dist()
+    torch.set_num_threads(os.cpu_count())
+    n = 64
+    spec = OPTSpec.opt_125m()
+    ckpt = structured_checkpoint(spec, 0)
+    rs = np.random.RandomState(11)
+    lens = np.clip(np.rint(np.exp(rs.normal(np.log(64), 0.9, n))), 3, 600).astype(np.int64)
+    lens[0], lens[1], lens[2], lens[3] = 1, 2, 1024, 700          # the shortest prompts, the benchmark's longest, a long one
+    g = torch.Generator().manual_seed(11)
+    T = int(lens.sum())
+    ids = torch.randint(4, spec.vocab_size, (T,), generator=g, dtype=torch.int64).numpy()
+    cu = np.zeros(n + 1, np.int32)
+    np.cumsum(lens, out=cu[1:])
+    ids[cu[:-1]] = 2
+    out = dict(ids=ids.astype(np.int32), cu_seqlens=cu, seed=np.int64(0))
+    pred = RefPredictor(spec, ckpt)
+    arrive = np.zeros(n, np.int32)
+    s_a, sgs_a, rec_a = run("a", "opt-xxx", pred, ids, cu, arrive, 1, 2048, 256, out)
+    scores = np.array([g_.aux_model_score for g_ in sgs_a], np.float64)
+    assert np.isfinite(scores).all()
+    out["ref_score"] = scores.astype(np.float32)
+    assert np.array_equal(out["ref_score"].astype(np.float64), scores)
+    keep = {k: v for k, v in out.items() if k in ("ids", "cu_seqlens", "seed", "ref_score", "a_order", "a_concat")}
+    # the size of the residual stream the reference saw (hidden state before the final LayerNorm, first and last request)
+    print(f"outlier: T = {T}, score range [{scores.min():.4f}, {scores.max():.4f}], smallest gap between sorted scores "
+          f"{np.diff(np.sort(scores)).min():.3e}; {pred.seconds:.1f} s in the reference predictor; cold order head "
+          f"{rec_a['order'][0][:8].tolist()}")
+    path = os.path.join(GOLD, "outlier_opt125m_64.npz")
+    np.savez_compressed(path, **keep)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "outlier":
+        return main_outlier()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "xpt":
         return main_xpt()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":

@@ -361,3 +361,25 @@ def test_install_surface_exists_on_the_reference_scheduler():
     assert attrs["scheduled_seq_groups[i].seq_group"] == "SequenceGroup"
     # the wiring's call pattern on the real scheduler: [score the arrivals,] order, age - once per step
     assert surf["calls"][:3] == [["obtain_aux_scores", 64], ["order", 64], ["age", 64, surf["calls"][2][2]]]
+
+
+def test_structured_checkpoint_fixture_from_the_reference():
+    """tests/golden/outlier_opt125m_64.npz (oracle/make_config1_golden.py --config outlier): the reference's own fp32 predictor
+    on a checkpoint with the structure of TRAINED OPT weights (massive embedding channels, LayerNorm gains in [0.2, 3], 5x
+    init scale), 64 requests incl. L = 1 / 2 / 1024, ordered by the reference's own Scheduler.  The oracle restates it to
+    fp32 rounding, and the literal sort of the oracle's scores differs from the reference's order only in fp32 near-ties."""
+    from vllm_ltr_amd.opt_spec import structured_checkpoint
+    z = np.load(os.path.join(GOLDEN, "outlier_opt125m_64.npz"), allow_pickle=False)
+    spec = OPTSpec.opt_125m()
+    ids, cu, ref = z["ids"].astype(np.int64), z["cu_seqlens"], z["ref_score"]
+    lens = np.diff(cu)
+    assert lens.min() == 1 and 2 in lens and lens.max() == 1024
+    got = OracleOPTScorer(spec, structured_checkpoint(spec, int(z["seed"]))).score(ids, cu)
+    err = float(np.abs(got - ref).max())
+    assert err <= 2e-5, err
+    want = z["a_order"][0]
+    want = want[want >= 0].tolist()
+    assert want == [int(r.request_id) for r in rs.opt_order([rs.Req(str(i), float(s)) for i, s in enumerate(ref)], -1, 0)]
+    mine = [int(r.request_id) for r in rs.opt_order([rs.Req(str(i), float(s)) for i, s in enumerate(got)], -1, 0)]
+    for a, b, gap in discordant_pairs(want, mine, ref):
+        assert gap <= 2 * err, (a, b, gap, err)

@@ -469,6 +469,20 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
 #ifdef LTR_GEMM_TIMELINE
   const unsigned long long tl1 = __builtin_readcyclecounter();
 #endif
+#ifdef LTR_GEMM_EPI_1IN8
+  // diag (wrong results; profiles/r05_k768_epilogue_bound.txt): in the two WIDE K = 768 shapes (QKV, fc1) only one tile in
+  // LTR_GEMM_EPI_1IN8 runs its epilogue, the others drop their accumulators - what the K loops alone cost, i.e. the most an
+  // epilogue that frees the accumulators early (and overlaps the next tile's K loop) could ever return
+  if (K == 768 && N >= 2304 && (blockIdx.x % LTR_GEMM_EPI_1IN8) != 0) {
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sink == 1.2345e-30f) ep.out_f32[0] = sink;     // (keeps the MFMAs alive; never true)
+    return;
+  }
+#endif
   // ---- epilogue through LDS: per-wave strip [16 rows][64 cols] f32 (row stride CLD), four
   // strips per wave (its four 16-row MFMA blocks).
   // Each wave touches only its own strip, so after ONE workgroup barrier (the K-loop's LDS reads
