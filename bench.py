@@ -581,12 +581,14 @@ def main():
             # on THESE kernel sources - the files carry the tag and the source hash of their pass
             sha = kernel_sources_sha16()
             traffic, traffic_src, pmc = None, None, None
-            tpath, ppath = os.path.join(ROOT, "profiles", "gemm_traffic.json"), os.path.join(ROOT, "profiles", "gemm_pmc.json")
+            # (taken on THESE kernel sources and on THIS workload: the headline workload's passes live in gemm_traffic.json /
+            # gemm_pmc.json, another workload's - BASELINE config 3 - in gemm_traffic.<model>_<profile>_<n>.json)
+            wl = f"{args.model}/{args.profile}/{n_local}"
+            suf = "" if wl == "125m/sharegpt/8192" else "." + wl.replace("/", "_")
+            tpath, ppath = os.path.join(ROOT, "profiles", f"gemm_traffic{suf}.json"), os.path.join(ROOT, "profiles", f"gemm_pmc{suf}.json")
             try:
                 tj = json.load(open(tpath))
                 traffic_src = tj.get("source")
-                # (taken on THESE kernel sources and on THIS workload: the PMC passes run the default 125m / sharegpt / 8k call)
-                wl = f"{args.model}/{args.profile}/{n_local}"
                 if traffic_src and traffic_src.get("kernel_sha16") == sha and traffic_src.get("workload", "125m/sharegpt/8192") == wl:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:

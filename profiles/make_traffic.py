@@ -21,6 +21,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def workload_suffix():
+    """'' for the headline workload (125m / sharegpt / 8192 per GPU), '.<model>_<profile>_<n>' otherwise: the PMC artefacts
+    of another workload (BASELINE config 3: 350m / lmsys / 8192) live in their own files (bench.py picks by workload)."""
+    w = os.environ.get("LTR_PROFILE_WORKLOAD", "125m/sharegpt/8192")
+    return "" if w == "125m/sharegpt/8192" else "." + w.replace("/", "_")
+
+
 def source_stamp():
     """Which kernels the pass measured: LTR_PROFILE_TAG (refresh_profiles.sh's tag) + the hash of the kernel sources
     (bench.py uses the numbers only while the hash still matches - same function there, kernel_sources_sha16)."""
@@ -93,7 +100,7 @@ def main():
                        fetch_correction=g["read_factor"], write_correction=g["write_factor"],
                        hbm_bytes_per_launch=g["hbm_bytes_per_launch"], source=source_stamp(),
                        note="see kernel_traffic.json; corrections measured by diag/pmc_calib.hip"),
-                  open("profiles/gemm_traffic.json", "w"), indent=1)
+                  open(f"profiles/gemm_traffic{workload_suffix()}.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -5,8 +5,13 @@
 #   3. SQ counters (MFMA busy, LDS bank conflicts, wave cycles) -> pmc_sq.txt
 #   4. the default bench line                          -> bench.json
 #   5. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv
-# usage: bash vllm_ltr_amd/csrc/diag/refresh_profiles.sh <tag>      (tag e.g. r02_v8); copy gpurun_out/<tag>/* to profiles/
+# usage: bash vllm_ltr_amd/csrc/diag/refresh_profiles.sh <tag> [bench workload flags]     (tag e.g. r02_v8); copy
+#        gpurun_out/<tag>/* to profiles/.  BASELINE config 3: ... <tag> --model 350m --profile lmsys with
+#        LTR_PROFILE_WORKLOAD=350m/lmsys/8192 (the PMC artefacts then go to profiles/gemm_traffic.350m_lmsys_8192.json etc.)
 TAG=${1:-r02}
+shift
+WL="$@"
+SUF=$(python -c "import os; w=os.environ.get('LTR_PROFILE_WORKLOAD','125m/sharegpt/8192'); print('' if w=='125m/sharegpt/8192' else '.'+w.replace('/','_'))")
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -17,7 +22,7 @@ cd /tmp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/vllm_ltr_amd/csrc/diag/pmc_calib.hip -o /tmp/pmc_calib || exit 1
 rocprofv3 --pmc FETCH_SIZE -d $O/calib_fetch -o f -- /tmp/pmc_calib > $O/calib_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/calib_write -o w -- /tmp/pmc_calib > $O/calib_w.log 2>&1
-BENCH="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-class-head --steady-new 0"
+BENCH="python $R/bench.py $WL --steps 1 --warmup 0 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-scale-points --no-class-head --steady-new 0"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- $BENCH > $O/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- $BENCH > $O/pmc_w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_sq -o s -- $BENCH > $O/pmc_s.log 2>&1
@@ -25,13 +30,13 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_l2 -o l -- $B
 cd $R
 db() { find $O/$1 -name "*.db" | head -1; }
 python profiles/make_traffic.py $(db pmc_fetch) $(db pmc_write) $(db calib_fetch) $(db calib_write) $O/kernel_traffic.json > $O/traffic.log 2>&1
-cp profiles/gemm_traffic.json $O/gemm_traffic.json
+cp profiles/gemm_traffic$SUF.json $O/gemm_traffic$SUF.json
 python profiles/summarize_pmc.py $(db pmc_sq) $(db pmc_l2) > $O/pmc_sq.txt 2>&1
-python profiles/make_gemm_pmc.py $(db pmc_sq) $(db pmc_l2) $O/gemm_pmc.json > /dev/null 2>&1
-cp $O/gemm_pmc.json profiles/gemm_pmc.json
-python bench.py > $O/bench.json 2> $O/bench.err
+python profiles/make_gemm_pmc.py $(db pmc_sq) $(db pmc_l2) $O/gemm_pmc$SUF.json > /dev/null 2>&1
+cp $O/gemm_pmc$SUF.json profiles/gemm_pmc$SUF.json
+python bench.py $WL > $O/bench.json 2> $O/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-class-head --steady-new 0 > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py $WL --steps 2 --warmup 1 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-scale-points --no-class-head --steady-new 0 > $O/prof.log 2>&1
 cd $R
 python profiles/summarize_rocpd.py $(db prof) $O/kernel_stats.csv > $O/kernel_stats.txt 2>&1
 find $O -name "*.db" -delete

@@ -360,6 +360,19 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+#ifdef LTR_GEMM_STAGGER
+  // lab (profiles/r05_k768_epilogue_bound.txt): de-phase the two workgroups that share a CU.  They start together, walk the same
+  // number of K-slabs and so reach their epilogues together (nobody on the CU issues MFMAs meanwhile); every later workgroup
+  // inherits the phase of the one whose slot it takes.  Half of the FIRST wave of workgroups (index inside the XCD & MASK, below
+  // 64) waits LTR_GEMM_STAGGER ticks of the 100 MHz clock before its first tile.
+  {
+    const int kx = blockIdx.x >> 3;
+    if (kx < 64 && (kx & LTR_GEMM_STAGGER_MASK) && gridDim.x >= 1024) {
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < LTR_GEMM_STAGGER) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+#endif
 
   // global_load_lds pieces of this lane per slab: one 16-row group of each activation plane
   // (rows wave*16 + (lane>>2)) and two 16-row groups of W (rows wave*32 + i*16 + (lane>>2))
