@@ -61,8 +61,9 @@ typedef struct ltr_model_desc {
  *                    operand x * gamma * 16 (which must stay inside fp16: LTR_E_RANGE).  The twin handle a caller falls back
  *                    to when ltr_status reports LTR_E_RANGE for a checkpoint with massive activations (plugin.py).
  *  LTR_F_NO_LANES    never run a call as two halves on two streams (see "Lanes" below).
- *  LTR_F_ONE_PASS    F16 mode with ONE fp16 MFMA pass per product: activations rounded to fp16 (the `lo` plane is neither
- *                    loaded nor multiplied), f32 accumulate - the arithmetic of the reference's own GPU path (fp16 model,
+ *  LTR_F_ONE_PASS    F16 mode with ONE fp16 MFMA pass per product, in the GEMMs and in the attention (q, k, v, p as plain
+ *                    fp16): activations rounded to fp16 (the `lo` plane is neither loaded nor multiplied, and not stored
+ *                    where every reader runs one pass), f32 accumulate - the arithmetic of the reference's own GPU path (fp16 model,
  *                    vllm/config.py:906-943; train/trainer.py:213-216).  Scores move by ~2e-3 against the fp32 predictor:
  *                    OUTSIDE the 1e-4 contract of the default mode; opt-in, reported as its own number by bench.py.
  *  LTR_F_LANES_UNPROBED  keep the first lane-stream candidate without the overlap probe (tests of the two-lane

@@ -268,7 +268,8 @@ struct ChunkRun {
     GemmArgs g = g0;
     if (m->one_pass) {     // LTR_F_ONE_PASS: hi plane only; lo planes that only another GEMM would read are not stored
       g.one_pass = 1;
-      g.no_lo_out = g.out_slab || g.ln_out.hi ? 1 : 0;     // fc1's ReLU output, the LayerNorm-fold operand (QKV's q|k|v goes to attention: kept)
+      g.no_lo_out = g.keep_lo_out ? 0 : 1;     // every reader of a split output runs one pass too (GEMMs, the MFMA attention) - except
+                                               // the last layer's K | V, which the VALU last-query kernel reads as hi + lo
     }
     // the dominant kernel (128 x 256 tiles) and the small-batch kernels are timed as separate classes
     ProfScope p(m, wd == LTR_W_F16 && gemm_small_config(g) >= 0 ? LTR_K_GEMM_SMALL : LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
@@ -329,7 +330,7 @@ int ChunkRun::layer(const int L) {
       AOp kv{ws.qkv.hi, (char*)ws.qkv.hi + (size_t)Tc * 2 * H * 2};
       {
         GemmArgs g{};
-        g.a = ws.a; g.w = m->last_kv_w; g.bias = qkv_b + H; g.out_split = kv;
+        g.a = ws.a; g.w = m->last_kv_w; g.bias = qkv_b + H; g.out_split = kv; g.keep_lo_out = 1;
         g.M = Tc; g.N = 2 * H; g.K = H; g.a_slab = 1;
         if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L] + H; g.bias = m->fold_d_qkv[L] + H; g.ln_parts = H / 64; }
         if ((rc = gemm(g))) return rc;
@@ -373,7 +374,7 @@ int ChunkRun::layer(const int L) {
       {
         ProfScope p(m, LTR_K_ATTN, 2.0 * sum_l2 * H, s);
         rc = launch_attention(m->dbg_attn_valu && wd == LTR_W_F16 ? -1 : wd, ws.qkv, cu_dev + r0, nreq, Tc, H, d.num_heads,
-                              ws.blk, ws.a, L == 0, s, nullptr, ws.blk_bytes);
+                              ws.blk, ws.a, L == 0, s, nullptr, ws.blk_bytes, m->one_pass && !m->dbg_attn_valu);
       }
       if (rc) return rc;
     }

@@ -233,7 +233,10 @@ __device__ unsigned long long g_attn_tl[4096 * 5];
 // merged through LDS at the end: nine tiles become three per wave.  128 KiB of LDS, one workgroup per CU.
 // (Dealing the tiles to the waves while everybody still loads every tile behind a barrier gains nothing: the barrier makes
 // each iteration as long as its one working wave.)
-template <int NW, bool SKV>
+// ONEP (LTR_F_ONE_PASS): q, k, v and p as plain fp16 - the hi planes only are streamed and multiplied (one MFMA pass per
+// product instead of three), the lo plane of the output is not stored (its reader, out_proj, runs one pass too): the
+// arithmetic of an fp16 flash attention, as in the reference's GPU predictor (rocm_flash_attn.py:244-290 on fp16 tensors).
+template <int NW, bool SKV, bool ONEP = false>
 __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
     const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qh[ks] = *reinterpret_cast<const f16x8*>(qkv_hi + qrow + ks * 16);
-      ql[ks] = *reinterpret_cast<const f16x8*>(qkv_lo + qrow + ks * 16);
+      if (!ONEP) ql[ks] = *reinterpret_cast<const f16x8*>(qkv_lo + qrow + ks * 16);
     }
   }
   f32x16 o[2];
@@ -289,9 +292,9 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
     const size_t rowoff = (size_t)(t0 + min(kt + lrow, L - 1)) * ld + head * D;
     __half* base = smem + stage * ATT_STAGE + wave * 8 * D;
     __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc_log * 8), (lds_void*)(base), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
+    if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + vc * 8), (lds_void*)(base + 2 * PLANE_H), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
+    if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
   };
 
   const int kend = min(L, qblk0 + QBLK);      // keys needed by this block: [0, kend)
@@ -308,9 +311,9 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
       const int kc = (lane & 7) ^ ((row >> 1) & 7), vcc = (lane & 7) ^ (((row >> 1) & 1) * LTR_ATTN_VSWZ);
       const size_t rowoff = (size_t)(t0 + min(kt + row, L - 1)) * ld + head * D;
       __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc * 8), (lds_void*)(base + r * 8 * D), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc * 8), (lds_void*)(base + PLANE_H + r * 8 * D), 16, 0, 0);
+      if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc * 8), (lds_void*)(base + PLANE_H + r * 8 * D), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + vcc * 8), (lds_void*)(base + 2 * PLANE_H + r * 8 * D), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vcc * 8), (lds_void*)(base + 3 * PLANE_H + r * 8 * D), 16, 0, 0);
+      if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vcc * 8), (lds_void*)(base + 3 * PLANE_H + r * 8 * D), 16, 0, 0);
     }
   };
   const int nown = SKV ? (ntile > wave ? (ntile - wave + NW - 1) / NW : 0) : 0;      // tiles of this wave's stream
@@ -325,19 +328,19 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
   // loop; left to itself it re-waits vmcnt(0) at their first use in every iteration, which also drains
   // the look-ahead tiles.
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qh[ks]), "v"(ql[ks]));
+  for (int ks = 0; ks < 4; ++ks) { if (ONEP) asm volatile("" ::"v"(qh[ks])); else asm volatile("" ::"v"(qh[ks]), "v"(ql[ks])); }
   for (int it = 0; it < (SKV ? nown : ntile); ++it) {
     const int kt = SKV ? (wave + NW * it) * TK : it * TK;
     const __half* s_khi;
     if (SKV) {
       // my tile `it` has landed once only my NEXT tile's 16 loads are outstanding; no workgroup barrier: nobody else
       // touches my ring
-      if (it + 1 < nown) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (it + 1 < nown) { if (ONEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       s_khi = smem + (wave * 2 + (it & 1)) * ATT_STAGE;
     } else {
-      if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it landed, it+1 may fly
+      if (it + 1 < ntile) { if (ONEP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // tile it landed, it+1 may fly
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // raw barrier: __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for the look-ahead tiles too
       __builtin_amdgcn_s_barrier();                       // everyone's rows landed; tile it-1 fully consumed
@@ -360,9 +363,11 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
     for (int ks = 0; ks < 4; ++ks) {
       const int c = 2 * ks + lh;
       const f16x8 kh = *reinterpret_cast<const f16x8*>(s_khi + k_off(lq, c));
-      const f16x8 kl = *reinterpret_cast<const f16x8*>(s_klo + k_off(lq, c));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc, 0, 0, 0);
+      if (!ONEP) {
+        const f16x8 kl = *reinterpret_cast<const f16x8*>(s_klo + k_off(lq, c));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc, 0, 0, 0);
+      }
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc, 0, 0, 0);
     }
     // ---- online softmax for query lq (this lane: 16 of its 32 keys; lane^32: the others).
@@ -396,8 +401,10 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
       psum += p0 + p1;
       const _Float16 h0 = (_Float16)p0, h1 = (_Float16)p1;
       ph0[i] = h0; ph1[i] = h1;
-      pl0[i] = (_Float16)(p0 - (float)h0);
-      pl1[i] = (_Float16)(p1 - (float)h1);
+      if (!ONEP) {
+        pl0[i] = (_Float16)(p0 - (float)h0);
+        pl1[i] = (_Float16)(p1 - (float)h1);
+      }
     }
     l += psum;
     // ---- O^T += V^T P^T  (rows = d, cols = queries).  A fragment of k-step g: element e of
@@ -415,14 +422,22 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
           const int key = 16 * g + 8 * hf + 4 * lh + ((lane & 15) >> 2);
           const int off = v_off(key, dt * 32 + (lane & 16) + (lane & 3) * 4);
           const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_vhi + off));
-          const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_vlo + off));
-          const f16x4 ah = __builtin_bit_cast(f16x4, a), bl = __builtin_bit_cast(f16x4, b);
+          const f16x4 ah = __builtin_bit_cast(f16x4, a);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { vh[4 * hf + e] = ah[e]; vl[4 * hf + e] = bl[e]; }
+          for (int e = 0; e < 4; ++e) vh[4 * hf + e] = ah[e];
+          if (!ONEP) {
+            const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_vlo + off));
+            const f16x4 bl = __builtin_bit_cast(f16x4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vl[4 * hf + e] = bl[e];
+          }
         }
-        const f16x8 ph = g ? ph1 : ph0, pl = g ? pl1 : pl0;
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+        const f16x8 ph = g ? ph1 : ph0;
+        if (!ONEP) {
+          const f16x8 pl = g ? pl1 : pl0;
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+        }
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
       }
     }
@@ -501,7 +516,7 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
     if (q0 + row < L) {
       const size_t ob = (size_t)(t0 + q0 + row) * H + head * D + opiece * 4;
       *reinterpret_cast<uint2*>(out_hi + ob) = vh;
-      *reinterpret_cast<uint2*>(out_lo + ob) = vl;
+      if (!ONEP) *reinterpret_cast<uint2*>(out_lo + ob) = vl;
     }
   }
 #ifdef LTR_ATTN_TIMELINE
@@ -956,7 +971,7 @@ int launch_attention_blocks(const int32_t* cu, int n_req, int qb, int32_t* blk_s
 }
 
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
-                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2, size_t blk_bytes) {
+                     int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2, size_t blk_bytes, int one_pass) {
   if (n_req == 0 || T == 0) return LTR_OK;
   if (H != n_heads * D) { set_error("attention: head size must be 64 (H=%d heads=%d)", H, n_heads); return LTR_E_INVAL; }
   const float scale_log2e = 0.125f * 1.4426950408889634f;   // d^-0.5 (opt.py:73) * log2(e)
@@ -978,14 +993,23 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
       LTR_LAUNCH_CHECK();
     }
     dim3 grid(T / qb + n_req, n_heads);   // sum ceil(L/qb) <= floor(T/qb) + n_req
+    if (one_pass && lse2 != nullptr) { set_error("attention: the one-pass variant has no training (lse2) form"); return LTR_E_INVAL; }
     if (skv) {
       constexpr int LDS = NW * 2 * ATT_STAGE * sizeof(__half);      // a private two-stage ring per wave: 128 KiB
       static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)attn_f16s_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+        return hipFuncSetAttribute((const void*)attn_f16s_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess &&
+               hipFuncSetAttribute((const void*)attn_f16s_kernel<NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
       }();
       (void)attr_ok;
-      attn_f16s_kernel<NW, true><<<grid, NW * 64, LDS, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
-                                                            n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+      if (one_pass)
+        attn_f16s_kernel<NW, true, true><<<grid, NW * 64, LDS, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
+                                                                    n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+      else
+        attn_f16s_kernel<NW, true><<<grid, NW * 64, LDS, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
+                                                              n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+    } else if (one_pass) {
+      attn_f16s_kernel<NW, false, true><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>(
+          (const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc, n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
     } else {
       attn_f16s_kernel<NW, false><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>(
           (const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc, n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);

@@ -99,6 +99,7 @@ struct GemmArgs {
   // no_lo_out: do not store the lo planes of out_split / ln_out either (their only reader is another one-pass GEMM)
   int one_pass = 0;
   int no_lo_out = 0;
+  int keep_lo_out = 0;   // (caller's note to ChunkRun::gemm: this output's lo plane has a reader that is not a one-pass kernel)
 };
 
 // launchers (each in its own .hip file)
@@ -132,7 +133,8 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu /*chunk-local, [n+1]
                      int build_blocks /*0: reuse the work list an earlier call built in blk_start for the same cu*/, hipStream_t s,
                      float* lse2 = nullptr /*[T, heads] log2-domain log-sum-exp of every query row (training), nullable*/,
                      size_t blk_bytes = 0 /*bytes behind blk_start when more than the minimum: (n_req+4)*4 + (T/32+n_req+1)*16
-                                            lets small passes run the split-K/V variant (32-query blocks)*/);
+                                            lets small passes run the split-K/V variant (32-query blocks)*/,
+                     int one_pass = 0 /*LTR_F_ONE_PASS: hi planes only, no lo output*/);
 
 int launch_attention_bwd_planes(const float* x, size_t n /*multiple of 8*/, void* planes /*[2][n] halves*/, hipStream_t s);
 // training: dqkv [T, 3H] of the attention block on the split-fp16 MFMA (ltr_attn.hip "attention BACKWARD")
