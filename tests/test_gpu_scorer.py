@@ -524,6 +524,24 @@ def test_plugin_tpt_and_xpt_orders(dev):
         m.output_len = g.output_len
     want = rs.xpt_order(mirror, key, value, lambda q: q.output_len)
     assert [g.request_id for g in got] == [m.request_id for m in want]
+    # `ltr` / `constraint` (scheduler.py:1020-1052; unbound in the reference's string table): sorted(key=-score), ties by
+    # position; `constraint` keeps scheduler.records = the sorted ranking scores (-score) of everything scored so far
+    from collections import deque
+    lr = MI355XRanker(sc, "opt-xxx-starv3-period2", max_length=100, mtype="class")   # (the starvation part does not apply)
+    fresh = [FakeSeqGroup(g.request_id, g.prompt_token_ids) for g in groups]
+
+    class Sched:
+        pass
+    s2 = Sched()
+    s2.waiting, s2.running, s2.swapped, s2.aux_model = deque(fresh[:30]), deque(), deque(), lr
+    got = lr.ordered_requests(s2, "constraint")
+    lit = sorted(list(s2.waiting), key=lambda q: -q.aux_model_score)
+    assert [g.request_id for g in got] == [g.request_id for g in lit]
+    assert s2.records == sorted(-g.aux_model_score for g in fresh[:30])
+    s2.waiting.extend(fresh[30:])
+    got = lr.ordered_requests(s2, "ltr")
+    assert [g.request_id for g in got] == [g.request_id for g in sorted(list(s2.waiting), key=lambda q: -q.aux_model_score)]
+    assert len(s2.records) == 30
 
 
 @pytest.mark.gpu

@@ -703,7 +703,9 @@ class MI355XRanker:
         return float(req.expected_length - out_len)
 
     def ordered_requests(self, scheduler, policy: Optional[str] = None) -> list:
-        """scheduler.py:969-1000 (and :936-948, :951-961, :1005-1015 for tpt/rtpt/ropt)."""
+        """scheduler.py:969-1000 (and :936-948, :951-961, :1005-1015 for tpt/rtpt/ropt; ``policy`` "ltr" / "constraint":
+        :1020-1052 - the same descending sort without starvation control, unbound in the reference's own string table;
+        "constraint" also keeps ``scheduler.records``, the sorted ranking scores of everything scored so far, :1031-1033)."""
         waiting = scheduler.waiting
         # unscored requests = the arrivals since the last call: a suffix of the waiting deque
         # (add_seq_group appends, scheduler.py:376; preempted requests are pushed to the FRONT and are scored
@@ -720,9 +722,11 @@ class MI355XRanker:
         if need:
             timed = int(os.environ.get("OPT_TIME", 0))                           # scheduler.py:977-982
             t0 = time.time()
-            scheduler.aux_model.obtain_aux_scores(need)
+            ret = scheduler.aux_model.obtain_aux_scores(need)
             if timed:
                 print("OPT-TIME: ", time.time() - t0)
+            if policy == "constraint":                                           # scheduler.py:1031-1033
+                scheduler.records = sorted(list(getattr(scheduler, "records", [])) + [-x for x in ret])
         reqs = list(waiting) + list(scheduler.running) + list(scheduler.swapped)
         try:
             out = self.order(reqs, policy)
