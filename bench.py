@@ -522,9 +522,11 @@ def main():
             c = mk(n_q)
             el, _ = c.timed(2, 1)
             lin_q, att_q = model_flops(spec, c.lens)
+            byt_q = compulsory_bytes(spec, int(c.cu[-1]), passes=max(1, -(-max(c.tokens_shard) // 196608)))
             scale_pts.append(dict(queue_total=n_q, tokens_total=int(c.cu[-1]), ms_per_call=el / 2 * 1e3, calls_per_s=2 / el,
                                   requests_per_s=n_q * 2 / el, sharded=c.is_sharded,
-                                  mfma_frac=(lin_q + att_q) / (el / 2) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world)))
+                                  mfma_frac=(lin_q + att_q) / (el / 2) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
+                                  hbm_frac_compulsory=byt_q / (el / 2) / 1e9 / (PEAK_HBM_GBS * world)))
             c.release(); del c
 
     # ---- class-mode head at the reference's largest bucket count (train/train.sh: 8,192 labels; opt.py:389-397): the

@@ -510,8 +510,14 @@ class MI355XRanker:
         self.scorer = twin
         if self._sharded is not None:
             self._sharded.scorer = twin
-        if self._pre_static is not None:                    # the captured graphs replay the folded handle's launches
+        if self.prescore:
+            # forwards started at arrival ran on the folded handle: any of them may be the one that overflowed (the flag does
+            # not say which), so none of their scores is trusted - the requests fall back to being scored in their step, on
+            # the twin; the captured graphs replay the folded handle's launches and are dropped as well
             self._pre_stream.synchronize()
+            for rec in self._pre_inflight:
+                self._prescore_retire(rec)
+            self._pre_inflight.clear()
             self._pre_static = None
 
     def _rescore_unfolded(self, seq_groups) -> List[float]:
