@@ -355,7 +355,9 @@ def test_install_surface_exists_on_the_reference_scheduler():
     attrs = surf["attributes"]
     src = inspect.getsource(MI355XRanker.install) + inspect.getsource(MI355XRanker.ordered_requests)
     touched = set(re.findall(r"scheduler\.(\w+)", src)) - {"py"}      # ("scheduler.py:NNN" citations in comments)
-    assigned_by_engine = {"aux_model", "distribution"}        # llm_engine.py:228-242; scheduler.py:312 (xpt only)
+    # llm_engine.py:228-242; scheduler.py:312 (xpt only); :315 `records` (xpt only; the unbound `constraint` order appends to it,
+    # :1031-1033 - the ranker reads it with getattr)
+    assigned_by_engine = {"aux_model", "distribution", "records"}
     assert touched - assigned_by_engine <= set(attrs), touched - set(attrs)
     assert attrs["_schedule"] == attrs["_general_schedule"] == "method" and attrs["waiting"] == "deque"
     assert attrs["scheduled_seq_groups[i].seq_group"] == "SequenceGroup"
