@@ -25,13 +25,19 @@ def _qkv(T, H, seed, scale_q):
 
 # split_kv: the 32-query split-K/V variant small passes run (each wave walks every fourth K/V tile as its own stream, the
 # four online-softmax states merged through LDS) against the 128-query kernel of full-size passes
+# split_kv = "wide": the 256-query / eight-wave workgroups (attn_f16s_kernel<8, ...>, LTR_ATTN_NW=8: one K/V tile in LDS serves
+# 256 queries), with 255 / 256 / 257-token requests at its block edge
 @pytest.mark.parametrize("model,mode,split_kv", [("125m", "f16", True), ("125m", "f16", False), ("350m", "f16", True),
-                                                  ("350m", "f16", False), ("125m", "f32", False)])
+                                                  ("350m", "f16", False), ("125m", "f32", False), ("125m", "f16", "wide"),
+                                                  ("350m", "f16", "wide")])
 @pytest.mark.parametrize("scale_q", [0.5, 4.0])
 def test_attention_kernel_alone_vs_oracle(model, mode, split_kv, scale_q, monkeypatch):
     from vllm_ltr_amd.scorer import HipOPTScorer
-    # the library reads the threshold once per process (default 600 tokens): this process tests the variant up to 2,048
+    # the library reads the threshold per call (default 600 tokens): this test runs the variant up to 2,048
     monkeypatch.setenv("LTR_ATTN_SPLITKV_TOKENS", "2048")
+    wide = split_kv == "wide"
+    monkeypatch.setenv("LTR_ATTN_NW", "8" if wide else "4")
+    split_kv = False if wide else split_kv
     spec = (OPTSpec.opt_125m() if model == "125m" else OPTSpec.opt_350m())
     spec1 = OPTSpec(**{**spec.__dict__, "num_hidden_layers": 1})          # the handle only supplies H / heads / mode
     ckpt = seeded_checkpoint(spec1, 0)
@@ -42,6 +48,8 @@ def test_attention_kernel_alone_vs_oracle(model, mode, split_kv, scale_q, monkey
     lens = LENS if mode == "f16" else [1, 31, 32, 33, 128, 129, 300]       # the f32 VALU kernel is the slow cross-check path
     if split_kv:
         lens = [1, 31, 32, 33, 128, 129, 161, 1024, 300]                   # (LTR_ATTN_SPLITKV_TOKENS below: the split-K/V kernel)
+    if wide:
+        lens = LENS + [255, 256, 257, 513]
     T = int(np.sum(lens))
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     x = _qkv(T, H, 3, scale_q)
@@ -68,7 +76,7 @@ def test_attention_kernel_alone_vs_oracle(model, mode, split_kv, scale_q, monkey
     scale = np.abs(want).max()
     worst = int(err.max(axis=1).argmax())
     req = int(np.searchsorted(cu, worst, side="right") - 1)
-    print(f"{model}/{mode}{' split-K/V' if split_kv else ''} q-scale {scale_q}: T = {T}, max|out - oracle| = {err.max():.3e} (|out| <= {scale:.2f}) at row {worst} "
+    print(f"{model}/{mode}{' split-K/V' if split_kv else (' 256-query' if wide else '')} q-scale {scale_q}: T = {T}, max|out - oracle| = {err.max():.3e} (|out| <= {scale:.2f}) at row {worst} "
           f"= position {worst - cu[req]} of a {lens[req]}-token request")
     # outputs are convex combinations of v ~ N(0, 1): absolute tolerance.  f16 path: products of split operands
     # (dropped lo.lo terms 2^-22) + an fp16 hi|lo output; f32 path: plain f32 arithmetic

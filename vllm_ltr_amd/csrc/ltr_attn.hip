@@ -236,8 +236,13 @@ __device__ unsigned long long g_attn_tl[4096 * 5];
 // ONEP (LTR_F_ONE_PASS): q, k, v and p as plain fp16 - the hi planes only are streamed and multiplied (one MFMA pass per
 // product instead of three), the lo plane of the output is not stored (its reader, out_proj, runs one pass too): the
 // arithmetic of an fp16 flash attention, as in the reference's GPU predictor (rocm_flash_attn.py:244-290 on fp16 tensors).
+// NW = 8 (round 5, lab: LTR_ATTN_NW=8): 256 queries per workgroup.  A request longer than 128 tokens is walked by several
+// 128-query workgroups, each of which streams the keys [0, its last query] again: 32 % (ShareGPT profile) to 54 % (LMSYS
+// profile) more q|k|v bytes than the tensors hold, at a kernel that runs at the fabric's copy rate.  With eight waves one K/V
+// tile in LDS serves 256 queries.  The per-wave code is unchanged (32 queries per wave); the tile loads are dealt to eight
+// waves instead of four (waves 0-3 the K planes, waves 4-7 the V planes).
 template <int NW, bool SKV, bool ONEP = false>
-__global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
+__global__ void __launch_bounds__(NW * 64, SKV ? 1 : (NW == 8 ? 4 : 3)) attn_f16s_kernel(
     const __half* __restrict__ qkv_hi, const __half* __restrict__ qkv_lo, const int32_t* __restrict__ cu,
     const int32_t* __restrict__ blk_start, const int4* __restrict__ blk_desc, int n_req, int H, float scale_log2e,
     __half* __restrict__ out_hi, __half* __restrict__ out_lo,
@@ -246,7 +251,8 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
   // LDS-DMA stores against every ds_read and drains vmcnt(0) in front of the first fragment read
   extern __shared__ __attribute__((aligned(16))) __half smem[];
   constexpr int QBLK = SKV ? 32 : 32 * NW;
-  static_assert(NW == 4, "load map below assumes 4 waves (one 8-row group of each plane per wave)");
+  static_assert(NW == 4 || (NW == 8 && !SKV), "load maps below: 4 waves (one 8-row group of each plane per wave) or 8 (K | V split)");
+  constexpr int LPT = (NW == 4 ? 4 : 2) / (ONEP ? 2 : 1);      // tile loads per wave (the counted vmcnt waits below)
 
 #ifdef LTR_ATTN_TIMELINE
   const unsigned long long tl0 = __builtin_readcyclecounter();
@@ -284,17 +290,24 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = NEG, l = 0.f;
 
-  // tile loads: wave w fills rows 8w..8w+7 of each of the four planes (1 KiB each)
-  const int lrow = wave * 8 + (lane >> 3);                      // key row inside the tile
+  // tile loads: NW = 4: wave w fills rows 8w..8w+7 of each of the four planes (1 KiB each); NW = 8: rows 8(w & 3).. of the
+  // two K planes (w < 4) or of the two V planes (w >= 4)
+  const int lw = wave & 3;
+  const bool load_k = NW == 4 || wave < 4, load_v = NW == 4 || wave >= 4;      // wave-uniform
+  const int lrow = lw * 8 + (lane >> 3);                        // key row inside the tile
   const int kc_log = (lane & 7) ^ ((lrow >> 1) & 7);            // K: swizzled source chunk
   const int vc = (lane & 7) ^ (((lrow >> 1) & 1) * LTR_ATTN_VSWZ);   // V: chunk bits flipped on odd row pairs (v_off)
   auto issue = [&](int stage, int kt) {
     const size_t rowoff = (size_t)(t0 + min(kt + lrow, L - 1)) * ld + head * D;
-    __half* base = smem + stage * ATT_STAGE + wave * 8 * D;
-    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc_log * 8), (lds_void*)(base), 16, 0, 0);
-    if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + vc * 8), (lds_void*)(base + 2 * PLANE_H), 16, 0, 0);
-    if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
+    __half* base = smem + stage * ATT_STAGE + lw * 8 * D;
+    if (load_k) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + H + kc_log * 8), (lds_void*)(base), 16, 0, 0);
+      if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + H + kc_log * 8), (lds_void*)(base + PLANE_H), 16, 0, 0);
+    }
+    if (load_v) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_hi + rowoff + 2 * H + vc * 8), (lds_void*)(base + 2 * PLANE_H), 16, 0, 0);
+      if (!ONEP) __builtin_amdgcn_global_load_lds((gbl_void*)(qkv_lo + rowoff + 2 * H + vc * 8), (lds_void*)(base + 3 * PLANE_H), 16, 0, 0);
+    }
   };
 
   const int kend = min(L, qblk0 + QBLK);      // keys needed by this block: [0, kend)
@@ -340,7 +353,7 @@ __global__ void __launch_bounds__(NW * 64, SKV ? 1 : 3) attn_f16s_kernel(
       __builtin_amdgcn_wave_barrier();
       s_khi = smem + (wave * 2 + (it & 1)) * ATT_STAGE;
     } else {
-      if (it + 1 < ntile) { if (ONEP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // tile it landed, it+1 may fly
+      if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");   // tile it landed, it+1 may fly
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // raw barrier: __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for the look-ahead tiles too
       __builtin_amdgcn_s_barrier();                       // everyone's rows landed; tile it-1 fully consumed
@@ -970,6 +983,11 @@ int launch_attention_blocks(const int32_t* cu, int n_req, int qb, int32_t* blk_s
   return LTR_OK;
 }
 
+namespace {
+// 256-query workgroups by default?  (lab rule, set from the measurements in profiles/r05_attn_wide.txt)
+inline bool attn_wide_default(int T, int n_req) { (void)T; (void)n_req; return false; }
+}  // namespace
+
 int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, int H, int n_heads,
                      int32_t* blk_start, AOp out, int build_blocks, hipStream_t s, float* lse2, size_t blk_bytes, int one_pass) {
   if (n_req == 0 || T == 0) return LTR_OK;
@@ -987,7 +1005,11 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
     const int skv_tokens = skv_env ? atoi(skv_env) : 600;
     const bool skv = lse2 == nullptr && T <= skv_tokens &&
                      blk_bytes >= (size_t)((n_req + 1 + 3) & ~3) * 4 + ((size_t)T / 32 + n_req + 1) * 16;
-    const int qb = skv ? 32 : 32 * NW;
+    // 256-query workgroups (8 waves; the kernel's NW = 8 note).  LTR_ATTN_NW: 4 / 8 force one, unset = the measured rule
+    const char* nw_s = getenv("LTR_ATTN_NW");                    // (read per call, like LTR_ATTN_SPLITKV_TOKENS: a test can move it)
+    const int nw_env = nw_s ? atoi(nw_s) : 0;
+    const bool wide = !skv && lse2 == nullptr && (nw_env == 8 || (nw_env == 0 && attn_wide_default(T, n_req)));
+    const int qb = skv ? 32 : (wide ? 256 : 32 * NW);
     if (build_blocks) {   // the work list depends on cu_seqlens only: built once per pass, reused by every layer
       attn_blocks_kernel<<<1, 1024, 0, s>>>(cu, n_req, qb, blk_start, blk_desc);
       LTR_LAUNCH_CHECK();
@@ -1007,6 +1029,19 @@ int launch_attention(int wdtype, AOp qkv, const int32_t* cu, int n_req, int T, i
       else
         attn_f16s_kernel<NW, true><<<grid, NW * 64, LDS, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc,
                                                               n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+    } else if (wide) {
+      constexpr int LDS8 = 8 * 2 * 32 * 136;                          // the output staging of eight waves (> the 48 KiB ring)
+      static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)attn_f16s_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8) == hipSuccess &&
+               hipFuncSetAttribute((const void*)attn_f16s_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8) == hipSuccess;
+      }();
+      (void)attr_ok;
+      if (one_pass)
+        attn_f16s_kernel<8, false, true><<<grid, 512, LDS8, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc, n_req, H,
+                                                                 scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
+      else
+        attn_f16s_kernel<8, false, false><<<grid, 512, LDS8, s>>>((const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc, n_req, H,
+                                                                  scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
     } else if (one_pass) {
       attn_f16s_kernel<NW, false, true><<<grid, NW * 64, NSTAGE * ATT_STAGE * sizeof(__half), s>>>(
           (const __half*)qkv.hi, (const __half*)qkv.lo, cu, blk_start, blk_desc, n_req, H, scale_log2e, (__half*)out.hi, (__half*)out.lo, lse2);
