@@ -142,6 +142,45 @@ def test_scoring_at_arrival_collects_the_same_scores():
     assert rk.metrics()["prescore"]["launches"] == m["launches"]
 
 
+def test_scoring_at_arrival_aborted_requests_do_not_pin_records():
+    """A request scored at arrival and then ABORTED (Scheduler.abort_seq_group, scheduler.py:379-413) never reaches
+    obtain_aux_scores.  Its record must not keep every later record - and their pinned staging buffers - alive:
+    with the `abort_request` hook it is forgotten at once, without it the sweep drops it PRESCORE_ORPHAN_S after its forward
+    finished; the requests around it are scored as always."""
+    import time
+    from util import FakeSeqGroup
+    from vllm_ltr_amd.plugin import MI355XRanker
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 6)
+    sc = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
+    lens = bench_lengths(40, seed=5, mu=30.0).clip(1, 150)
+    ids, cu = synthetic_batch(spec, lens.tolist(), 3)
+    groups = [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(len(lens))]
+    want = MI355XRanker(sc, "opt", max_length=150).obtain_aux_scores(
+        [FakeSeqGroup(g.request_id, g.prompt_token_ids) for g in groups])
+    rk = MI355XRanker(sc, "opt", max_length=150, prescore=True)
+    for g in groups:                                    # 40 lone arrivals = 40 records
+        rk.add_request(g)
+        rk._pre_stream.synchronize()
+        time.sleep(0.006)
+    assert len(rk._pre_inflight) == 40
+    hooked, silent = groups[0], groups[1]               # the two OLDEST records: exactly what used to block the list
+    rk.abort_request(hooked)
+    alive = groups[2:]
+    got = rk.obtain_aux_scores(alive)
+    assert np.abs(np.array(got) - np.array(want[2:])).max() <= 2e-6 * max(1.0, float(np.abs(want).max()))
+    assert len(rk._pre_inflight) == 1 and rk._pre_inflight[0]["left"] == 1          # only the silently aborted one is left
+    assert getattr(hooked, "_ltr_pre", None) is None and hooked.aux_model_score is None
+    rk._pre_inflight[0]["t"] -= 2 * rk.PRESCORE_ORPHAN_S                            # ... until it is old enough
+    rk._prescore_sweep()
+    assert len(rk._pre_inflight) == 0 and rk.metrics()["prescore"]["orphans"] == 1
+    assert getattr(silent, "_ltr_pre", None) is None
+    assert len(rk._pre_free_stagers) <= rk.PRESCORE_MAX_STAGERS
+    # should the "aborted" request show up in a step after all, the step scores it itself
+    assert abs(rk.obtain_aux_scores([silent])[0] - want[1]) <= 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
 def test_scoring_at_arrival_graph_buckets():
     """A lone arrival's forward is replayed from a captured graph, one per 64-token bucket, the prompt padded to the bucket
     by a dummy request (plugin.py `_prescore_graph`).  Prompt lengths around every bucket edge, the shortest and the longest
