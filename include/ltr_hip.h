@@ -128,7 +128,8 @@ size_t ltr_workspace_bytes(ltr_handle h /* may be NULL for LTR_WS_RANK */, int32
 /* Tokens processed per internal pass of ltr_score (request-aligned chunks keep the
  * activations of a pass resident in the 256 MiB Infinity Cache).  0 restores the default. */
 int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens);
-/* Lanes.  A scoring call of 1,200 ... 49,152 tokens (a scheduler step with tens to hundreds of arrivals) runs as two
+/* Lanes.  A mid-sized scoring call - from 2.1 M activation elements per layer (2,735 tokens at H = 768, 2,051 at H = 1024) to
+ * 49,152 tokens: a scheduler step with tens to hundreds of arrivals - runs as two
  * request-aligned halves on two streams - the caller's and one the handle owns - joined before the call returns control of
  * the caller's stream: ordering on `stream` is what it is without them, the scores are those of the two halves scored on
  * their own, and ltr_workspace_bytes accounts for the second set of activations (a smaller workspace is not an error: the

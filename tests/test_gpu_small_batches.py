@@ -60,12 +60,14 @@ def test_scores_do_not_depend_on_the_batch_size_regime(model):
 
 
 @pytest.mark.parametrize("model", ["125m", "tiny_post_ln"])
-def test_two_lanes_score_what_the_two_halves_score_alone(model):
-    """A call of 1,200 ... 49,152 tokens runs as two request-aligned halves on two streams (ltr_api.hip run_forward, "lanes";
-    include/ltr_hip.h).  Each half is the call one would make for it alone: the scores must be BIT-identical to scoring the
-    halves in two calls (which, below 1,200 tokens each, run on one lane), the call must be counted as a two-lane call, and
-    a following call on the same stream must see the finished scores (the join)."""
+def test_two_lanes_score_what_the_two_halves_score_alone(model, monkeypatch):
+    """A mid-sized call (by default from 2.1 M activation elements per layer - 2,735 tokens at H = 768 - to 49,152 tokens; here
+    the lower end is moved to 1,200 tokens with LTR_LANES_MIN so that the halves stay small) runs as two request-aligned halves on
+    two streams (ltr_api.hip run_forward, "lanes"; include/ltr_hip.h).  Each half is the call one would make for it alone: the
+    scores must be BIT-identical to scoring the halves in two calls (which, below 1,200 tokens each, run on one lane), the call
+    must be counted as a two-lane call, and a following call on the same stream must see the finished scores (the join)."""
     from vllm_ltr_amd.scorer import HipOPTScorer
+    monkeypatch.setenv("LTR_LANES_MIN", "1200")
     spec = {"125m": OPTSpec.opt_125m, "tiny_post_ln": OPTSpec.tiny_post_ln}[model]()
     # (lanes="unprobed": the arithmetic of the two halves does not depend on whether the process's hardware queues let them
     # overlap - a production handle drops the second lane when they do not, include/ltr_hip.h "Lanes")
@@ -225,7 +227,7 @@ def test_scoring_at_arrival_graph_buckets():
 
 
 @pytest.mark.parametrize("warm", [False, True])
-def test_scoring_at_arrival_graph_buckets_in_the_two_lane_range(warm):
+def test_scoring_at_arrival_graph_buckets_in_the_two_lane_range(warm, monkeypatch):
     """Buckets of >= 1,216 tokens fall into the range where an eager call runs as two halves on two streams, split at a point
     taken from the HOST copy of cu_seqlens - which a graph would freeze at the first arrival's length (a
     later, longer prompt of the same bucket then read rows that were never computed).  A call that is being captured runs on
@@ -236,6 +238,7 @@ def test_scoring_at_arrival_graph_buckets_in_the_two_lane_range(warm):
     from util import FakeSeqGroup
     from vllm_ltr_amd.plugin import MI355XRanker
     from vllm_ltr_amd.scorer import HipOPTScorer
+    monkeypatch.setenv("LTR_LANES_MIN", "1200")          # (the default lower end scales with 1 / H: 16k tokens for this tiny model)
     spec = dataclasses.replace(OPTSpec.tiny_pre_ln(), max_position_embeddings=2048)
     ckpt = seeded_checkpoint(spec, 21)
     sc = HipOPTScorer(spec, ckpt, "cuda:0", "f16")
@@ -262,13 +265,14 @@ def test_scoring_at_arrival_graph_buckets_in_the_two_lane_range(warm):
     sc.check_status()
 
 
-def test_concurrent_callers_on_one_handle():
+def test_concurrent_callers_on_one_handle(monkeypatch):
     """Two host threads score different batches on ONE handle at the same time, each with its own workspace, output and
     stream (include/ltr_hip.h allows it; the engine's async loop and a warm-up thread can meet like this).  The handle owns
     one second lane: the caller that finds it taken runs on one lane.  Every call must return what it returns alone."""
     import threading
     from vllm_ltr_amd import _lib
     from vllm_ltr_amd.scorer import HipOPTScorer
+    monkeypatch.setenv("LTR_LANES_MIN", "1200")          # (these 2.4k-token batches of a tiny model must be lane-sized)
     spec = OPTSpec.tiny_pre_ln()
     sc = HipOPTScorer(spec, seeded_checkpoint(spec, 3), "cuda:0", "f16")
     dev = torch.device("cuda:0")

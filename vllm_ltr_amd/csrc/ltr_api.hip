@@ -129,13 +129,19 @@ inline int head_block_rows(int lpad) {
 // passes of at most this many rows get the small-batch split-K scratch (launch_gemm decides per launch)
 constexpr int64_t SPLITK_MAX_ROWS = 4800;
 
-// Lanes (run_forward): batches of 1,200 .. 49,152 tokens run as two halves on two streams.  LTR_LANES: 0 never, 1 (default)
-// in that range, 2 whenever the batch has two requests (lab); LTR_LANES_MIN / LTR_LANES_MAX move the range.  Measured
-// (profiles/r04_lanes_lab.txt): -4 ... -11 % per call between 1.4k and 44k tokens (OPT-125m and OPT-350m), +-1 % from 64k up.
+// Lanes (run_forward): mid-sized batches run as two halves on two streams.  LTR_LANES: 0 never, 1 (default) in the range below,
+// 2 whenever the batch has two requests (lab); LTR_LANES_MIN / LTR_LANES_MAX move the range (tokens).  Measured
+// (profiles/r04_lanes_lab.txt, profiles/r05_lanes_threshold.txt): -4 ... -14 % per call from ~2,750 tokens (OPT-125m) / ~2,100
+// (OPT-350m) to 44k tokens, +-1 % from 64k up; BELOW that the halves pick kernels sized for ~1k rows and two lanes lose 2-17 % in
+// most of the range (round 4's lower end of 1,200 tokens came from a coarse grid that happened to hit the winning points):
+// the lower end is 2.1 M activation elements per layer, i.e. 2,735 tokens at H = 768 and 2,051 at H = 1024.
 inline int lanes_mode() { static const int v = [] { const char* e = getenv("LTR_LANES"); return e ? atoi(e) : 1; }(); return v; }
-inline bool lanes_for_tokens(int64_t T) {
-  static const int64_t lo = [] { const char* e = getenv("LTR_LANES_MIN"); return e ? atoll(e) : 1200; }();
-  static const int64_t hi = [] { const char* e = getenv("LTR_LANES_MAX"); return e ? atoll(e) : 49152; }();
+inline bool lanes_for_tokens(int64_t T, int H) {
+  // (read per call - a getenv costs nothing next to a scoring call - so that a test can move the range)
+  const char* e_lo = getenv("LTR_LANES_MIN");
+  const char* e_hi = getenv("LTR_LANES_MAX");
+  const int64_t lo_env = e_lo ? atoll(e_lo) : -1, hi = e_hi ? atoll(e_hi) : 49152;
+  const int64_t lo = lo_env >= 0 ? lo_env : (2100000 + H - 1) / (H > 0 ? H : 1);
   return lanes_mode() >= 2 || (lanes_mode() == 1 && T >= lo && T <= hi);
 }
 
@@ -793,7 +799,7 @@ size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
     int64_t Tc = T < chunk_cap(h) ? T : chunk_cap(h);
     int64_t Nc = N < Tc ? N : Tc;
     const size_t one = carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold, head_mode(h)).bytes;
-    if (h->lane_stream && T <= chunk_cap(h) && N >= 2 && lanes_for_tokens(T)) {
+    if (h->lane_stream && T <= chunk_cap(h) && N >= 2 && lanes_for_tokens(T, h->d.hidden_size)) {
       // two lanes: the cut is the request boundary closest to the middle, so a half holds at most T / 2 tokens plus half
       // a request of maximal length - and at most as many requests as tokens
       int64_t Th = T / 2 + (h->d.pos_rows - 2 + 1) / 2 + 1;
@@ -934,7 +940,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
       if (hipStreamIsCapturing(s, &cst) != hipSuccess) (void)hipGetLastError();
       capturing = cst != hipStreamCaptureStatusNone;
     }
-    if (!hidden_out && r0 == 0 && r1 == N && N >= 2 && h->lane_stream && !capturing && lanes_for_tokens(t1 - t0)) {
+    if (!hidden_out && r0 == 0 && r1 == N && N >= 2 && h->lane_stream && !capturing && lanes_for_tokens(t1 - t0, d.hidden_size)) {
       const int64_t half = (t1 - t0) / 2;
       r_mid = 1;
       while (r_mid + 1 < N && cu[r_mid + 1] - t0 <= half) ++r_mid;              // first cut at or past the middle ...
