@@ -35,7 +35,8 @@ labels over 256 requests, i.e. ties everywhere, broken by ``"10" < "9"``.  Also 
 ``--config outlier`` writes ``tests/golden/outlier_opt125m_64.npz``: the reference's fp32 predictor on a checkpoint with the
 structure of TRAINED OPT weights (``opt_spec.structured_checkpoint``: 5x init scale, two massive embedding channels at
 +40 / -55, LayerNorm gains in [0.2, 3]) - 64 requests incl. L = 1, 2 and 1024 - and the order of one cold scheduler step
-(``opt``, no starvation) the reference's own Scheduler returns for those scores.
+(``opt``, no starvation) the reference's own Scheduler returns for those scores.  ``--config outlier350``: the same for the
+OPT-350m shape (post-LN blocks, project_in / project_out; 48 requests) -> ``tests/golden/outlier_opt350m_48.npz``.
 
 Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
 """
@@ -337,14 +338,16 @@ def main_xpt():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
 
-def main_outlier():
-    """OPT-125m shape, structured checkpoint, 64 requests: reference fp32 scores + the reference Scheduler's cold order."""
+def main_outlier(family="125m"):
+    """OPT-125m (or, ``--config outlier350``, OPT-350m: post-LN blocks, project_in / project_out) shape, structured
+    checkpoint, 64 (48) requests: reference fp32 scores + the reference Scheduler's cold order."""
     from vllm_ltr_amd.opt_spec import structured_checkpoint
     mg._init_dist()
     torch.set_num_threads(os.cpu_count())
-    n = 64
-    spec = OPTSpec.opt_125m()
-    ckpt = structured_checkpoint(spec, 0)
+    n = 64 if family == "125m" else 48
+    spec = OPTSpec.opt_125m() if family == "125m" else OPTSpec.opt_350m()
+    from vllm_ltr_amd.opt_spec import STRUCTURED_350M
+    ckpt = structured_checkpoint(spec, 0) if family == "125m" else structured_checkpoint(spec, 0, **STRUCTURED_350M)
     rs = np.random.RandomState(11)
     lens = np.clip(np.rint(np.exp(rs.normal(np.log(64), 0.9, n))), 3, 600).astype(np.int64)
     lens[0], lens[1], lens[2], lens[3] = 1, 2, 1024, 700          # the shortest prompts, the benchmark's longest, a long one
@@ -367,7 +370,7 @@ def main_outlier():
     print(f"outlier: T = {T}, score range [{scores.min():.4f}, {scores.max():.4f}], smallest gap between sorted scores "
           f"{np.diff(np.sort(scores)).min():.3e}; {pred.seconds:.1f} s in the reference predictor; cold order head "
           f"{rec_a['order'][0][:8].tolist()}")
-    path = os.path.join(GOLD, "outlier_opt125m_64.npz")
+    path = os.path.join(GOLD, "outlier_opt125m_64.npz" if family == "125m" else "outlier_opt350m_48.npz")
     np.savez_compressed(path, **keep)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
@@ -375,6 +378,8 @@ def main_outlier():
 def main():
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "outlier":
         return main_outlier()
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "outlier350":
+        return main_outlier("350m")
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "xpt":
         return main_xpt()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":

@@ -365,18 +365,22 @@ def test_install_surface_exists_on_the_reference_scheduler():
     assert surf["calls"][:3] == [["obtain_aux_scores", 64], ["order", 64], ["age", 64, surf["calls"][2][2]]]
 
 
-def test_structured_checkpoint_fixture_from_the_reference():
-    """tests/golden/outlier_opt125m_64.npz (oracle/make_config1_golden.py --config outlier): the reference's own fp32 predictor
-    on a checkpoint with the structure of TRAINED OPT weights (massive embedding channels, LayerNorm gains in [0.2, 3], 5x
-    init scale), 64 requests incl. L = 1 / 2 / 1024, ordered by the reference's own Scheduler.  The oracle restates it to
-    fp32 rounding, and the literal sort of the oracle's scores differs from the reference's order only in fp32 near-ties."""
-    from vllm_ltr_amd.opt_spec import structured_checkpoint
-    z = np.load(os.path.join(GOLDEN, "outlier_opt125m_64.npz"), allow_pickle=False)
-    spec = OPTSpec.opt_125m()
+@pytest.mark.parametrize("family", ["125m", "350m"])
+def test_structured_checkpoint_fixture_from_the_reference(family):
+    """tests/golden/outlier_opt125m_64.npz / outlier_opt350m_48.npz (oracle/make_config1_golden.py --config outlier /
+    outlier350): the reference's own fp32 predictor on checkpoints with the structure of TRAINED OPT weights (massive embedding
+    channels at +40 / -55, LayerNorm gains in [0.2, 3]; the pre-LN family also at 5x the init scale), requests incl. L = 1 / 2 /
+    1024, ordered by the reference's own Scheduler.  The oracle restates them to fp32 rounding, and the literal sort of the
+    oracle's scores differs from the reference's order only in fp32 near-ties."""
+    from vllm_ltr_amd.opt_spec import STRUCTURED_350M, structured_checkpoint
+    name, spec, kw = (("outlier_opt125m_64.npz", OPTSpec.opt_125m(), {}) if family == "125m" else
+                      ("outlier_opt350m_48.npz", OPTSpec.opt_350m(), STRUCTURED_350M))
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     ids, cu, ref = z["ids"].astype(np.int64), z["cu_seqlens"], z["ref_score"]
     lens = np.diff(cu)
     assert lens.min() == 1 and 2 in lens and lens.max() == 1024
-    got = OracleOPTScorer(spec, structured_checkpoint(spec, int(z["seed"]))).score(ids, cu)
+    assert float(ref.max() - ref.min()) > 0.05                       # (the scores still depend on the prompt)
+    got = OracleOPTScorer(spec, structured_checkpoint(spec, int(z["seed"]), **kw)).score(ids, cu)
     err = float(np.abs(got - ref).max())
     assert err <= 2e-5, err
     want = z["a_order"][0]

@@ -155,18 +155,25 @@ def seeded_checkpoint(spec: OPTSpec, seed: int = 0, std: float = 0.02,
     return out
 
 
-def structured_checkpoint(spec: OPTSpec, seed: int = 0) -> Dict[str, np.ndarray]:
+# parameters of the OPT-350m structured fixture (see structured_checkpoint)
+STRUCTURED_350M = dict(outlier=(40.0, -55.0), std=0.02, qk_std=0.06)
+
+
+def structured_checkpoint(spec: OPTSpec, seed: int = 0, outlier=(40.0, -55.0), std: float = 0.1,
+                          qk_std: float = 0.15) -> Dict[str, np.ndarray]:
     """A seeded fp16 checkpoint with the STRUCTURE trained OPT predictors have and N(0, 0.02) weights lack: weights at 5x the
     init scale (q / k at 7.5x: peaked attention), two "massive activation" channels in the token and position embeddings
     (offsets +40 and -55 with a spread of 3), LayerNorm gains spread over [0.2, 3] - the residual stream spans three orders
-    of magnitude and the LayerNorm statistics are dominated by two channels.  Used by the reference-run fixture
-    ``tests/golden/outlier_opt125m_64.npz`` (oracle/make_config1_golden.py --config outlier) and its GPU test."""
-    out = seeded_checkpoint(spec, seed, std=0.1, qk_std=0.15)
+    of magnitude and the LayerNorm statistics are dominated by two channels.  Used by the reference-run fixtures
+    ``tests/golden/outlier_opt125m_64.npz`` / ``outlier_opt350m_48.npz`` (oracle/make_config1_golden.py --config outlier /
+    outlier350; the post-LN family keeps the init scale of the weights - ``STRUCTURED_350M`` - because a deep post-LN stack with
+    3-5x weights forgets its input: the 48 reference scores came out within 2e-4 of each other) and their GPU tests."""
+    out = seeded_checkpoint(spec, seed, std=std, qk_std=qk_std)
     rs = np.random.RandomState(seed + 1000)
     for name in ("model.decoder.embed_tokens.weight", "model.decoder.embed_positions.weight"):
         w = out[name].astype(np.float32)
         ch = [3, 17] if w.shape[1] > 17 else [0, 1]
-        w[:, ch] += 3.0 * rs.standard_normal((w.shape[0], 2)).astype(np.float32) + np.array([40.0, -55.0], np.float32)
+        w[:, ch] += 3.0 * rs.standard_normal((w.shape[0], 2)).astype(np.float32) + np.array(outlier, np.float32)
         out[name] = w.astype(np.float16)
     for name in list(out):
         if name.endswith("layer_norm.weight"):
