@@ -149,28 +149,30 @@ def _worker_driver_mode(rank, world, port, q):
             served = sh.serve()
             q.put((rank, "worker", served, log))
             return
-        out = {}
-        r = np.random.RandomState(5)
-        for name, n in (("big", 64), ("small", 7), ("big2", 41)):
-            lens = r.randint(1, 40, n).tolist()
-            ids, cu = synthetic_batch(spec, lens, 2 + n)          # ONLY the driver has the batch
+        try:
+            out = {}
+            r = np.random.RandomState(5)
+            for name, n in (("big", 64), ("small", 7), ("big2", 41)):
+                lens = r.randint(1, 40, n).tolist()
+                ids, cu = synthetic_batch(spec, lens, 2 + n)          # ONLY the driver has the batch
+                ids_d, cu_d = torch.from_numpy(ids), torch.from_numpy(cu)
+                got = sh.score_from_driver(ids_d, cu_d, cu).numpy().copy()
+                coll = sh.last_call_collective
+                code = sh.agree_status(0) if coll else 0           # (what MI355XRanker._check_status does after a collective call)
+                out[name] = (bool(np.abs(got - orc.score(ids, cu)).max() < 1e-6), coll, code)
+            # a worker's shard overflows the folded operand: the agreed code is 2 on the driver, which re-scores on the twins
+            lens = r.randint(1, 40, 50).tolist()
+            ids, cu = synthetic_batch(spec, lens, 99)
             ids_d, cu_d = torch.from_numpy(ids), torch.from_numpy(cu)
             got = sh.score_from_driver(ids_d, cu_d, cu).numpy().copy()
-            coll = sh.last_call_collective
-            code = sh.agree_status(0) if coll else 0           # (what MI355XRanker._check_status does after a collective call)
-            out[name] = (bool(np.abs(got - orc.score(ids, cu)).max() < 1e-6), coll, code)
-        # a worker's shard overflows the folded operand: the agreed code is 2 on the driver, which re-scores on the twins
-        lens = r.randint(1, 40, 50).tolist()
-        ids, cu = synthetic_batch(spec, lens, 99)
-        ids_d, cu_d = torch.from_numpy(ids), torch.from_numpy(cu)
-        got = sh.score_from_driver(ids_d, cu_d, cu).numpy().copy()
-        code = sh.agree_status(0)
-        first_nan = bool(np.isnan(got).any())
-        sh.scorer = sh.scorer.unfolded_twin(); sh.unfolded = True
-        got = sh.score_from_driver(ids_d, cu_d, cu).numpy().copy()
-        code2 = sh.agree_status(0)
-        out["range"] = (bool(np.abs(got - orc.score(ids, cu)).max() < 1e-6), first_nan, code, code2)
-        sh.stop_workers()
+            code = sh.agree_status(0)
+            first_nan = bool(np.isnan(got).any())
+            sh.scorer = sh.scorer.unfolded_twin(); sh.unfolded = True
+            got = sh.score_from_driver(ids_d, cu_d, cu).numpy().copy()
+            code2 = sh.agree_status(0)
+            out["range"] = (bool(np.abs(got - orc.score(ids, cu)).max() < 1e-6), first_nan, code, code2)
+        finally:
+            sh.stop_workers()           # (whatever happens above: the passive rank's serve() loop must end)
         q.put((rank, "driver", out, log))
     finally:
         dist.destroy_process_group()

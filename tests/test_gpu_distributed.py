@@ -143,7 +143,6 @@ def _worker_driver_mode(rank, world, port, q):
             served = ranker.serve()
             q.put((rank, "worker", served, ranker.scorer.ln_fold, sc.lane_calls()))
             return
-        # driver: a checkpoint whose folded operand overflows is used for the SECOND ranker below
         n = 700
         lens = bench_lengths(n, seed=5, mu=24.0).clip(1, 150)
         ids, cu = synthetic_batch(spec, lens.tolist(), 6)
@@ -152,25 +151,27 @@ def _worker_driver_mode(rank, world, port, q):
         single = sc.score_device(torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev), cu).cpu().numpy()
         ranker = MI355XRanker(sc, "opt-xxx-starv3-period2", max_length=160, group=dist.group.WORLD, driver_rank=driver,
                               min_requests_to_shard=64, collective_timeout_s=120.0, prescore=True)
-        groups = [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(n)]
+        try:
+            groups = [FakeSeqGroup(str(i), ids[cu[i]:cu[i + 1]].tolist()) for i in range(n)]
 
-        class Sched:
-            pass
-        s = Sched()
-        s.waiting, s.running, s.swapped = deque(groups[:600]), deque(), deque()
-        ranker.install(s)
-        order = [g.request_id for g in s._get_ordered_requests()]              # 600 arrivals: sharded, the worker takes part
-        collective_calls = ranker._sharded.calls_served
-        for g in groups[600:610]:                                              # a few arrivals: scored at arrival / below the
-            ranker.add_request(g)                                              # threshold - the worker never hears of them
-            s.waiting.append(g)
-        order2 = [g.request_id for g in s._get_ordered_requests()]
-        small_calls = ranker._sharded.calls_served - collective_calls
-        for g in groups[610:]:
-            s.waiting.append(g)
-        order3 = [g.request_id for g in s._get_ordered_requests()]             # 90 more: sharded again
-        got = np.array([g.aux_model_score for g in groups], np.float32)
-        ranker.close()
+            class Sched:
+                pass
+            s = Sched()
+            s.waiting, s.running, s.swapped = deque(groups[:600]), deque(), deque()
+            ranker.install(s)
+            order = [g.request_id for g in s._get_ordered_requests()]              # 600 arrivals: sharded, the worker takes part
+            collective_calls = ranker._sharded.calls_served
+            for g in groups[600:610]:                                              # a few arrivals: scored at arrival / below the
+                ranker.add_request(g)                                              # threshold - the worker never hears of them
+                s.waiting.append(g)
+            order2 = [g.request_id for g in s._get_ordered_requests()]
+            small_calls = ranker._sharded.calls_served - collective_calls
+            for g in groups[610:]:
+                s.waiting.append(g)
+            order3 = [g.request_id for g in s._get_ordered_requests()]             # 90 more: sharded again
+            got = np.array([g.aux_model_score for g in groups], np.float32)
+        finally:
+            ranker.close()              # (whatever happens above: the worker's serve() loop must end)
         q.put((rank, "driver", _same(got, single), collective_calls, small_calls, ranker._sharded.calls_served,
                sorted(order3) == sorted(g.request_id for g in groups) and len(order) == 600 and len(order2) == 610))
     finally:
