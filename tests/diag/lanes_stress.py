@@ -1,6 +1,6 @@
 """diag: soak of the two-lane forward under concurrency (not collected by pytest).  Random batches of 2 ... 96 requests, both
 model families at true width, the lanes handle (two halves on two streams) against a one-lane handle of the same checkpoint:
-equal to the 3e-6 of the batch-size regimes, the lanes handle deterministic over repeats - with and without an unrelated
+equal to the few 1e-6 of the batch-size regimes (bound 8e-6), the lanes handle deterministic over repeats - with and without an unrelated
 stream that keeps the GPU busy (a serving engine's backbone kernels run beside the ranker's).
     python tests/diag/lanes_stress.py [seconds]"""
 import os
@@ -45,7 +45,7 @@ while time.time() - t0 < budget:
     scale = max(1.0, float(np.abs(want).max()))
     err = max(float(np.abs(g - want).max()) for g in got)
     worst = max(worst, err / scale)
-    assert err <= 3e-6 * scale, (spec.hidden_size, k, int(cu[-1]), used, noisy, err)
+    assert err <= 8e-6 * scale, (spec.hidden_size, k, int(cu[-1]), used, noisy, err)
     assert all(np.array_equal(got[0], g) for g in got[1:]), (spec.hidden_size, k, int(cu[-1]), used, "not deterministic")
     n_calls += 3
     n_lane += used

@@ -1,5 +1,6 @@
 #!/bin/bash
 # lab (round 5): what do the parts of the post-LN fold's RLN epilogue cost on BASELINE config 3?
+# (apply diag/rln_probe.patch first: it adds the LTR_RLN_PROBE macros to ltr_gemm.hip)
 # Builds of ltr_gemm.hip with -DLTR_RLN_PROBE=<bits> (wrong results): 1 = the residual LayerNorm's gamma / beta as constants (no
 # loads in the strip loop), 2 = no statistics combine in the tile prologue (LNC and RLN), 4 = the RLN instances run the ordinary
 # one-sweep epilogue (no LayerNorm of the residual at all: the most ANY rewrite of the RLN epilogue could return).

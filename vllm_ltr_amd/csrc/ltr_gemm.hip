@@ -436,13 +436,9 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   issue(0, 0);
   if ((LNM == LNC || RLN) && tid < BM) {
     const int row = min(m0 + tid, M - 1);
-#if defined(LTR_RLN_PROBE) && (LTR_RLN_PROBE & 2)   // lab (wrong results; profiles/r05_rln_probe.txt): no statistics combine in the prologue
-    reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] = make_float2(0.f * row, 1.f);
-#else
     reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] =
         RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f)
             : combine_row_stats(ep.stats_in + row, ep.n_part, ep.ldm, 1.f / LN_FOLD_SCALE);
-#endif
   }
   for (int kt = 0; kt < nk; ++kt) {
 #ifdef LTR_GEMM_TIMELINE
@@ -519,13 +515,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
     bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
   }
-#if defined(LTR_RLN_PROBE) && (LTR_RLN_PROBE & 4)
-  constexpr bool RLN_E = false;
-#else
-  constexpr bool RLN_E = RLN;
-#endif
   float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;      // LNP: gamma * scale; LNC: c_n
-  if ((LNM == LNP || LNM == LNC) && !RLN_E && ccol < N) {              // (RLN instances fetch it in their second sweep)
+  if ((LNM == LNP || LNM == LNC) && !RLN && ccol < N) {                // (RLN instances fetch it in their second sweep)
     const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
     lnv_a = *reinterpret_cast<const float4*>(src + ccol);
     lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
@@ -544,11 +535,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
       for (int e = 0; e < 4; ++e) s_c[(4 * (lane >> 4) + e) * CLD + j * 16 + (lane & 15)] = acc[st][j][e];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-#if defined(LTR_RLN_PROBE) && (LTR_RLN_PROBE & 4)   // lab (wrong results): the RLN instances run the ordinary one-sweep epilogue (residual = x)
-    if (false) {
-#else
     if (ccol < N && RLN) {
-#endif
       // LayerNorm'd residual in TWO sweeps over the strip.  Everything at once - two rows of accumulator + residual in
       // flight, the affine vectors of the residual's LayerNorm, bias, the producer's gamma - does not fit the 128-VGPR
       // budget of four waves per SIMD: the compiler spilled, and the spilled LNP + RLN instance produced NaNs (its
@@ -574,11 +561,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         const float2 rst = reinterpret_cast<const float2*>(smem + 2 * STAGE)[min(gr[it], M - 1) - m0];
         {
           const float4 va = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol);
-#if defined(LTR_RLN_PROBE) && (LTR_RLN_PROBE & 1)   // lab (wrong results): the affine vectors of the residual's LayerNorm as constants
-          const float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
           const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol);
-#endif
           float4 x;
           x.x = va.x + bias_a.x + ((ra[it].x - rst.x) * rst.y * g.x + b.x);
           x.y = va.y + bias_a.y + ((ra[it].y - rst.x) * rst.y * g.y + b.y);
@@ -588,11 +571,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         }
         {
           const float4 vb = *reinterpret_cast<const float4*>(s_c + srow * CLD + ecol_b);
-#if defined(LTR_RLN_PROBE) && (LTR_RLN_PROBE & 1)
-          const float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
           const float4 g = *reinterpret_cast<const float4*>(ep.r_gamma + ccol_b), b = *reinterpret_cast<const float4*>(ep.r_beta + ccol_b);
-#endif
           float4 x;
           x.x = vb.x + bias_b.x + ((rb[it].x - rst.x) * rst.y * g.x + b.x);
           x.y = vb.y + bias_b.y + ((rb[it].y - rst.x) * rst.y * g.y + b.y);
@@ -647,8 +626,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         float2 st2 = make_float2(0.f, 0.f);
         if (LNM == LNC || RLN) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
         if (LNM == LNS) st2 = out_scale_stat(ep);
-        epilogue_piece<LNM, RLN_E>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, st2, gr[it], ccol,
-                                   ccol_b, o[it], ep.ldm, lane, tn * 4 + wc);
+        epilogue_piece<LNM, RLN>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, st2, gr[it], ccol,
+                                 ccol_b, o[it], ep.ldm, lane, tn * 4 + wc);
       }
     }
     __builtin_amdgcn_wave_barrier();
