@@ -359,3 +359,19 @@ def _measure_steady(sc, spec, dev, queue, need, ones, out, ks=(1, 16, 64), score
         out[k] = ms[len(ms) // 2]
         if scores is not None:
             scores[k] = queue._score[:k].cpu().numpy().copy()
+
+
+def test_two_lane_calls_soak_with_a_busy_gpu():
+    """tests/diag/lanes_stress.py for 20 s: random batches of 2 ... 96 requests of OPT-125m and OPT-350m through a two-lane handle
+    against a one-lane handle (8e-6: the batch-size regimes), three times each (bit-identical), half of them while an unrelated
+    stream keeps the GPU busy - a serving engine's backbone runs beside the ranker.  Round 5 met a fault that only this sees: a
+    change of code SHAPE in the split-K reduce kernel of the post-LN fold (same values) returned scores off by 1e-2 ... 2e-1 when,
+    and only when, two kernels of different streams were in flight (profiles/r05_rln_probe.txt)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "lanes_stress.py"), "20"], capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "lanes stress ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
+    print(r.stdout.strip().splitlines()[-1])
