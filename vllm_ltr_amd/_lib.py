@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libltr_hip.so")
+# LTR_LIB (diag): another build of the same library (lab variants of one kernel file); there is still no fallback
+LIB_PATH = os.environ.get("LTR_LIB") or os.path.join(_HERE, "csrc", "libltr_hip.so")
 
 LTR_W_F32, LTR_W_F16 = 0, 1
 LTR_WS_SCORE, LTR_WS_RANK = 0, 1
