@@ -891,3 +891,30 @@ def test_wider_opt_shapes_two_layers(dev, name, hidden, ffn, heads, pre_ln, embe
         del os.environ["LTR_NO_LN_FOLD"]
     assert np.abs(plain.score(ids, cu) - got).max() <= 2e-5
 
+
+@pytest.mark.parametrize("model", ["125m", "350m"])
+def test_row_statistics_combined_once_per_launch_are_invisible(dev, model, monkeypatch):
+    """LayerNorm fold, large passes (>= 8,192 rows): the (mean, M2) pieces a producer GEMM wrote are combined ONCE by
+    `row_stats_combine_kernel` into (mean, rstd) per row, and the consuming tiles (QKV / fc1 consumers, the post-LN blocks'
+    LayerNorm'd residual) load one float2 per row instead of gathering 12-16 pieces in front of their first barrier.  Same
+    function on the same inputs: the scores must be BIT-identical to the in-tile combine (LTR_STATS_COMB_MIN switches it off)."""
+    from util import bench_lengths
+    spec = OPTSpec.opt_125m() if model == "125m" else OPTSpec.opt_350m()
+    sc = _scorer(spec, seeded_checkpoint(spec, 2), dev, "f16")
+    lens = bench_lengths(150, seed=4, mu=80.0)
+    ids, cu = synthetic_batch(spec, lens.tolist(), 8)
+    assert int(cu[-1]) >= 2 * 8192 // 2 + 4096                      # one pass of well over 8,192 rows (one lane or two halves of > 4k)
+    monkeypatch.setenv("LTR_LANES_MAX", "0")                        # one lane: the whole batch is ONE pass of > 8,192 rows
+    monkeypatch.setenv("LTR_STATS_COMB_MIN", "1000000000")
+    base = sc.score(ids, cu)
+    monkeypatch.setenv("LTR_STATS_COMB_MIN", "8192")
+    comb = sc.score(ids, cu)
+    monkeypatch.setenv("LTR_STATS_COMB_MIN", "1")                   # (every pass, also the compact last-token rows)
+    comb1 = sc.score(ids, cu)
+    assert np.array_equal(base, comb) and np.array_equal(base, comb1)
+    want = OracleOPTScorer(spec, seeded_checkpoint(spec, 2)).score(*_first(ids, cu, 6))
+    assert np.abs(comb[:6] - want).max() <= TOL
+
+
+def _first(ids, cu, n):
+    return ids[:cu[n]], cu[:n + 1]

@@ -362,16 +362,18 @@ def _measure_steady(sc, spec, dev, queue, need, ones, out, ks=(1, 16, 64), score
 
 
 def test_two_lane_calls_soak_with_a_busy_gpu():
-    """tests/diag/lanes_stress.py for 20 s: random batches of 2 ... 96 requests of OPT-125m and OPT-350m through a two-lane handle
-    against a one-lane handle (8e-6: the batch-size regimes), three times each (bit-identical), half of them while an unrelated
-    stream keeps the GPU busy - a serving engine's backbone runs beside the ranker.  Round 5 met a fault that only this sees: a
-    change of code SHAPE in the split-K reduce kernel of the post-LN fold (same values) returned scores off by 1e-2 ... 2e-1 when,
-    and only when, two kernels of different streams were in flight (profiles/r05_rln_probe.txt)."""
+    """tests/diag/lanes_stress.py for 60 s: random batches of 2 ... 96 requests of OPT-125m and OPT-350m through a two-lane handle (on
+    the default stream, and on a side stream with its own scratch as scoring at arrival does) against a one-lane handle on an idle
+    device (8e-6: the batch-size regimes), three times each (bit-identical), half of them while an unrelated stream runs library fp16
+    and bf16 GEMMs - a serving engine's backbone runs beside the ranker.  That co-runner is what exposed round 5's fault: a
+    packed-f32 operand-select form that MI355X mis-executes in lanes 48-63 beside such a GEMM (profiles/r06_rln_fault.txt; the
+    build's ISA lint keeps the form out of the library, tests/test_gpu_isa_hazard.py holds the reproducers).  The seed is printed
+    (LTR_FUZZ_SEED replays a red run)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "lanes_stress.py"), "20"], capture_output=True,
-                       text=True, timeout=600, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "diag", "lanes_stress.py"), "60"], capture_output=True,
+                       text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "lanes stress ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
     print(r.stdout.strip().splitlines()[-1])

@@ -55,7 +55,12 @@ def build(force: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # the build checks its own output: no packed-f32 instruction of the form MI355X mis-executes beside a library fp16 GEMM
+    # (isa_lint.py, profiles/r06_rln_fault.txt)
+    from . import isa_lint
+    isa_lint.check([LIB])
     _build_tools(force)
+    _build_standalone(force)
     return LIB
 
 
@@ -65,6 +70,12 @@ TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip"),
          "gemm_bench": os.path.join("diag", "gemm_bench.hip"),
          # the GEMMs of two half batches on two streams against the whole batch on one (the "lanes" of run_forward)
          "lanes_probe": os.path.join("diag", "lanes_probe.hip")}
+# reproducers of the round-5 concurrency fault (profiles/r06_rln_fault.txt); they compile ltr_gemm.hip into themselves and use
+# rocBLAS as the co-running library GEMM: name -> (source, extra flags)
+ROCBLAS = os.path.exists("/opt/rocm/lib/librocblas.so") and os.path.exists("/opt/rocm/include/rocblas/rocblas.h")
+STANDALONE = {"pk_opsel_probe": (os.path.join("diag", "pk_opsel_probe.hip"), []),
+              "rln_fault": (os.path.join("diag", "rln_fault.hip"), []),
+              "rln_fault_r5": (os.path.join("diag", "rln_fault.hip"), ["-DLTR_RLN_FAULT_SHAPE"])}
 
 
 def _build_tools(force: bool) -> None:
@@ -80,6 +91,28 @@ def _build_tools(force: bool) -> None:
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+
+
+
+
+def _build_standalone(force: bool) -> None:
+    out_dir = os.path.join(HERE, "build")
+    os.makedirs(out_dir, exist_ok=True)
+    if not ROCBLAS:
+        return
+    def one(item):
+        name, (src, extra) = item
+        exe = os.path.join(out_dir, name)
+        deps = [os.path.join(HERE, src), os.path.join(HERE, "ltr_gemm.hip")] + [os.path.join(HERE, h) for h in HEADERS]
+        if force or _stale(exe, deps):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-Wno-unused-function", "-DWITH_ROCBLAS", *extra,
+                   "-I" + HERE, "-I" + os.path.join(HERE, "..", "..", "include"), os.path.join(HERE, src), "-L/opt/rocm/lib", "-lrocblas",
+                   "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    with ThreadPoolExecutor(max_workers=len(STANDALONE)) as ex:
+        list(ex.map(one, STANDALONE.items()))
 
 
 if __name__ == "__main__":

@@ -10,6 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#ifdef WITH_ROCBLAS
+#include <rocblas/rocblas.h>
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -41,7 +44,18 @@ __global__ void __launch_bounds__(256) victim(const float4* __restrict__ r, cons
                      "s_nop 0\n\t"
                      "v_pk_fma_f32 %1, %1, %4, %6"
                      : "+v"(a0), "+v"(a1) : "v"(s), "v"(g0), "v"(g1), "v"(b0), "v"(b1));
-      else
+      else if (MODE == 3) {
+        v2f sy = {s2.y, s2.y};
+        asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "v_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "v_pk_mul_f32 %0, %0, %7 op_sel_hi:[1,0]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_fma_f32 %0, %0, %3, %5\n\t"
+                     "v_pk_mul_f32 %1, %1, %7 op_sel_hi:[1,0]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_fma_f32 %1, %1, %4, %6"
+                     : "+v"(a0), "+v"(a1) : "v"(s), "v"(g0), "v"(g1), "v"(b0), "v"(b1), "v"(sy));
+      } else
         asm volatile("v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
                      "v_pk_mul_f32 %0, %0, %2 op_sel:[0,1]\n\t"
                      "v_pk_fma_f32 %0, %0, %3, %5\n\t"
@@ -111,10 +125,18 @@ int main(int argc, char** argv) {
     (void)hipMemsetAsync(dout, 0xff, n * 16, sa);
     if (mode == 0) victim<0><<<2048, 256, 0, sa>>>(dr, ds, dg, db, dout, n);
     else if (mode == 1) victim<1><<<2048, 256, 0, sa>>>(dr, ds, dg, db, dout, n);
-    else victim<2><<<2048, 256, 0, sa>>>(dr, ds, dg, db, dout, n);
+    else if (mode == 2) victim<2><<<2048, 256, 0, sa>>>(dr, ds, dg, db, dout, n);
+    else victim<3><<<2048, 256, 0, sa>>>(dr, ds, dg, db, dout, n);
   };
-  const char* aggr_name[] = {"none", "mfma", "valu", "mem", "lds", "mfma (few waves)"};
-  for (int mode = 0; mode < 3; ++mode) {
+#ifdef WITH_ROCBLAS
+  rocblas_handle rh; rocblas_create_handle(&rh); rocblas_set_stream(rh, sb);
+  const int G = 2048;
+  void *gz, *gc_;
+  (void)hipMalloc(&gz, (size_t)G * G * 2); (void)hipMalloc(&gc_, (size_t)G * G * 2);
+  (void)hipMemset(gz, 0, (size_t)G * G * 2);
+#endif
+  const char* aggr_name[] = {"none", "mfma", "valu", "mem", "lds", "mfma (few waves)", "library fp16 GEMM"};
+  for (int mode = 0; mode < 4; ++mode) {
     run_victim(mode);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(ref.data(), dout, n * 16, hipMemcpyDeviceToHost);
@@ -128,7 +150,12 @@ int main(int argc, char** argv) {
       for (int c = 0; c < 4; ++c) if (!(__builtin_fabsf(w[c] - gq[c]) <= 1e-6f * (1 + __builtin_fabsf(w[c])))) ++host_bad;
     }
     printf("mode %d: idle run vs host (sampled): %ld bad\n", mode, host_bad);
-    for (int ag = 0; ag < 6; ++ag) {
+#ifdef WITH_ROCBLAS
+    const int n_ag = 7;
+#else
+    const int n_ag = 6;
+#endif
+    for (int ag = 0; ag < n_ag; ++ag) {
       long bad_runs = 0, bad_elems = 0, by_comp[4] = {0, 0, 0, 0}, by_quarter[4] = {0, 0, 0, 0};
       for (int it = 0; it < rounds; ++it) {
         (void)hipDeviceSynchronize();
@@ -137,6 +164,14 @@ int main(int argc, char** argv) {
         if (ag == 3) aggr_mem<<<1024, 256, 0, sb>>>(dsrc, sink, (size_t)64 << 20, 3);
         if (ag == 4) aggr_lds<<<2048, 256, 0, sb>>>(sink, 200000);
         if (ag == 5) aggr_mfma<<<256, 256, 0, sb>>>(sink, 160000);
+#ifdef WITH_ROCBLAS
+        if (ag == 6) {
+          const float one = 1.f, nul = 0.f;
+          for (int k = 0; k < 30; ++k)
+            rocblas_gemm_ex(rh, rocblas_operation_none, rocblas_operation_none, G, G, G, &one, gz, rocblas_datatype_f16_r, G, gz, rocblas_datatype_f16_r, G, &nul,
+                            gc_, rocblas_datatype_f16_r, G, gc_, rocblas_datatype_f16_r, G, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+        }
+#endif
         run_victim(mode);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(got.data(), dout, n * 16, hipMemcpyDeviceToHost);

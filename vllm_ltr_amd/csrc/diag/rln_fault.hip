@@ -1,13 +1,17 @@
-// Diagnostic (round 6): kernel-level reproducer of the concurrency-dependent wrong-score fault of round 5
-// (profiles/r05_rln_probe.txt, profiles/r06_rln_fault.txt).  Includes ltr_gemm.hip itself (the kernels live in an anonymous
-// namespace), so that one kernel instance can be launched on FIXED inputs next to unrelated work on another stream:
-//   E1  splitk_epilogue_kernel<LNP, true> alone, inputs written once and never touched again -> any wrong output is the
-//       kernel's own doing (not a producer whose stores are not visible yet);
-//   E2  the fc2 launch of an OPT-350m layer through launch_gemm (128 x 256 kernel in 4 K parts + the reduce kernel);
-//   E3  E2's launch pair on two streams at once (the lanes of run_forward), each with its own buffers.
-// Every run is compared bit for bit with the same launch made on an idle device.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I<dir of the ltr_gemm.hip to test> -I<repo>/include diag/rln_fault.hip -o rln_fault
-//   rln_fault [iters] [M]
+// Diagnostic (round 6): kernel-level reproducer of round 5's "concurrency-dependent wrong scores" (profiles/r05_rln_probe.txt;
+// root cause in profiles/r06_rln_fault.txt: a packed-f32 operand-select form that MI355X mis-executes in lanes 48-63 while a library
+// fp16 GEMM shares the CU).  Includes ltr_gemm.hip itself (the kernels live in an anonymous namespace), so that ONE kernel
+// instance can be launched on FIXED inputs - written once by the host, never touched again - next to unrelated work on another
+// stream; every run is compared bit for bit with the same launch on an idle device:
+//   E1  splitk_epilogue_kernel<LNP, true> beside a streaming kernel (b) / another lane's fc2 launch (c);
+//   E2  the fc2 launch of an OPT-350m layer through launch_gemm (128 x 256 kernel in 4 K parts + the reduce kernel) beside (b);
+//   E3  E2's launch pair on two streams at once (the lanes of run_forward), each with its own buffers;
+//   E4  the reduce kernel beside a long MFMA kernel of our own (an 8,192-row GEMM);
+//   E5  the reduce kernel beside LIBRARY fp16 GEMMs (rocBLAS; -DWITH_ROCBLAS) - the co-runner a serving engine's backbone is, and
+//       the only one that exposes the fault: built with -DLTR_RLN_FAULT_SHAPE (round 5's expression: `v_pk_mul_f32 ... op_sel:[0,1]`
+//       in the kernel) 7-11 of 20 runs differ, 160-2,400 values each; the shipped expression: 0.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DLTR_RLN_FAULT_SHAPE] -DWITH_ROCBLAS -I<csrc> -I<repo>/include diag/rln_fault.hip -lrocblas
+//   rln_fault [iters] [M] [quick]         quick: E5 only.  Exit code 1 when any run differs.
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -149,6 +153,7 @@ static long compare(const char* tag, int it, const Bufs& b, const Snap& ref, con
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 200;
   const int M = argc > 2 ? atoi(argv[2]) : 1383;
+  const bool quick = argc > 3 && !strcmp(argv[3], "quick");
   const int N = 1024, K = 4096;
   hipStream_t sa, sb, sn;
   (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
@@ -185,7 +190,8 @@ int main(int argc, char** argv) {
   }
   printf("E1a done, bad so far %ld\n", bad);
   // ---- E1b: the same beside the noise kernel on another stream
-  long e1b = 0;
+  long e1b = 0, e1c = 0, e2 = 0, e3 = 0, e4 = 0, e5_total = 0;
+  if (!quick) {
   for (int it = 0; it < iters; ++it) {
     reset_outputs(A, sa);
     (void)hipStreamSynchronize(sa);
@@ -196,7 +202,6 @@ int main(int argc, char** argv) {
   }
   printf("E1b: %ld of %d runs differ\n", e1b, iters);
   // ---- E1c: the same beside B's whole fc2 launch on stream sb
-  long e1c = 0;
   for (int it = 0; it < iters; ++it) {
     reset_outputs(A, sa); reset_outputs(B, sb);
     (void)hipDeviceSynchronize();
@@ -207,7 +212,6 @@ int main(int argc, char** argv) {
   }
   printf("E1c: %ld of %d runs differ\n", e1c, iters);
   // ---- E2: the whole fc2 launch beside the noise kernel
-  long e2 = 0;
   for (int it = 0; it < iters; ++it) {
     reset_outputs(A, sa);
     (void)hipMemsetAsync(A.splitk, 0xff, A.splitk_bytes, sa);
@@ -219,7 +223,6 @@ int main(int argc, char** argv) {
   }
   printf("E2: %ld of %d runs differ\n", e2, iters);
   // ---- E3: two lanes, alternately issued (a: GEMM parts, b: GEMM parts + reduce interleave as launch_gemm issues them)
-  long e3 = 0;
   for (int it = 0; it < iters; ++it) {
     reset_outputs(A, sa); reset_outputs(B, sb);
     (void)hipMemsetAsync(A.splitk, 0xff, A.splitk_bytes, sa);
@@ -234,7 +237,6 @@ int main(int argc, char** argv) {
   printf("E3: %ld of %d runs differ\n", e3, iters);
   // ---- E4: the reduce kernel on fixed inputs beside a LONG MFMA kernel of another stream (a 8,192-row fc2 on the 128 x 256 kernel,
   // three launches ~ 1 ms): the reduce's waves share SIMDs with MFMA waves for their whole life
-  long e4 = 0;
   {
     Bufs Cb = make_bufs(8192, N, K, 3);
     GemmArgs gc = fc2_args(Cb);
@@ -252,6 +254,7 @@ int main(int argc, char** argv) {
     }
     printf("E4: %ld of %d runs differ\n", e4, iters);
   }
+  }   // !quick
 #ifdef WITH_ROCBLAS
   // ---- E5: the reduce kernel on fixed inputs beside library fp16 GEMMs (what a serving engine's backbone runs; torch's matmul
   // was the co-runner that exposed the round-5 fault): random operands and all-zero operands (same kernel, far less power)
@@ -280,9 +283,10 @@ int main(int argc, char** argv) {
         e5 += d != 0; waves += d;
       }
       printf("E5 (%s operands): %ld of %d runs differ (%ld values)\n", zero ? "zero" : "random", e5, iters, waves);
+      e5_total += e5;
     }
   }
 #endif
-  printf("rln_fault: E1b %ld E1c %ld E2 %ld E3 %ld E4 %ld of %d\n", e1b, e1c, e2, e3, e4, iters);
-  return (bad || e1b || e1c || e2 || e3 || e4) ? 1 : 0;
+  printf("rln_fault: E1b %ld E1c %ld E2 %ld E3 %ld E4 %ld E5 %ld of %d runs differ\n", e1b, e1c, e2, e3, e4, e5_total, iters);
+  return (bad || e1b || e1c || e2 || e3 || e4 || e5_total) ? 1 : 0;
 }

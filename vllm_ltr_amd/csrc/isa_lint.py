@@ -1,0 +1,90 @@
+"""ISA lint of the built gfx950 code objects: no packed-f32 instruction may select the HIGH register of src1 for its lo lane.
+
+Why (profiles/r06_rln_fault.txt): on MI355X, `v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32` with `op_sel[1] = 1, op_sel[0] = 0`
+(`op_sel:[0,1]`, `op_sel:[0,1,x]`) return a wrong lo half - the src1 term reads as zero - in lanes 48-63 whenever waves of a
+library fp16 GEMM kernel share the CU; every other operand-select placement (`[1,0]`, `[1,1]`, any `op_sel_hi`, src2) computes
+correctly in the same test (diag/pk_opsel_probe.hip: 4 of 4 runs, ~130,000 wrong values per 16 M; 0 for the other forms).
+hipcc emits the form when the y component of a float2 that lives in ONE 64-bit register (a 64-bit load, a phi of float2)
+feeds vectorised f32 math; round 5 met it as "scores off by 1e-2 whenever another stream has a kernel in flight" in one
+kernel instance.  The hazard is invisible to the compiler, so the build checks its own output:
+
+    python -m vllm_ltr_amd.csrc.isa_lint [file.so | file.o ...]      (default: the library and every object next to it)
+
+`build.py` runs this after linking and refuses a library that contains the form.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+
+# packed-f32 VOP3P with op_sel of src0 clear and of src1 set (the lo lane of src1 comes from the high register of the pair)
+_BAD = re.compile(r"\b(v_pk_(?:mul|add|fma)_f32)\b[^\n;]*\bop_sel:\[0,1(?:,[01])?\]")
+_LABEL = re.compile(r"^[0-9a-f]+ <([^>]+)>:")
+
+
+def device_code_objects(path: str, workdir: str) -> list[str]:
+    """Extract the gfx950 code objects embedded in a host ELF (.o / .so); a bare code object is returned as it is."""
+    with open(path, "rb") as f:
+        head = f.read(20)
+    if head[:4] == b"\x7fELF" and head[18:20] == b"\xe0\x00":          # e_machine 224: AMDGPU
+        return [path]
+    base = os.path.basename(path)
+    local = os.path.join(workdir, base)
+    if not os.path.exists(local):
+        os.symlink(os.path.abspath(path), local)
+    r = subprocess.run([OBJDUMP, "--offloading", base], cwd=workdir, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"llvm-objdump --offloading {path} failed:\n{r.stderr}")
+    return sorted(os.path.join(workdir, f) for f in os.listdir(workdir) if f.startswith(base + ".") and "amdgcn" in f)
+
+
+def lint_code_object(co: str) -> list[tuple[str, str]]:
+    r = subprocess.run([OBJDUMP, "-d", co], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"llvm-objdump -d {co} failed:\n{r.stderr}")
+    found, kernel = [], "?"
+    for line in r.stdout.splitlines():
+        m = _LABEL.match(line)
+        if m:
+            kernel = m.group(1)
+            continue
+        if _BAD.search(line):
+            found.append((kernel, line.split("//")[0].strip()))
+    return found
+
+
+def lint(paths: list[str]) -> list[tuple[str, str, str]]:
+    out = []
+    with tempfile.TemporaryDirectory() as wd:
+        for p in paths:
+            cos = device_code_objects(p, wd)
+            if not cos:
+                raise RuntimeError(f"{p}: no gfx950 code object found")
+            for co in cos:
+                out += [(os.path.basename(p), k, ins) for k, ins in lint_code_object(co)]
+    return out
+
+
+def check(paths: list[str]) -> None:
+    bad = lint(paths)
+    if bad:
+        lines = "\n".join(f"  {f}: {k}: {ins}" for f, k, ins in bad[:20])
+        raise RuntimeError(
+            f"ISA lint: {len(bad)} packed-f32 instruction(s) select the high register of src1 for the lo lane (op_sel:[0,1...]) - wrong "
+            f"results in lanes 48-63 beside a library fp16 GEMM on MI355X (profiles/r06_rln_fault.txt).  Keep the y component of a "
+            f"64-bit float2 out of vectorised f32 math (pass it through `asm volatile(\"\" : \"+v\"(y))` first):\n{lines}")
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:] or [os.path.join(HERE, "libltr_hip.so")]
+    bad = lint(args)
+    for f, k, ins in bad:
+        print(f"{f}: {k}: {ins}")
+    print(f"isa_lint: {len(bad)} finding(s) in {len(args)} file(s)")
+    sys.exit(1 if bad else 0)

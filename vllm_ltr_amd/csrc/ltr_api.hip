@@ -126,6 +126,14 @@ inline int head_block_rows(int lpad) {
   return (int)(r < 256 ? 256 : (r > (1 << 20) ? (1 << 20) : r)) / 128 * 128;
 }
 
+// LayerNorm fold: from this many rows on the row statistics a producer GEMM wrote are combined ONCE (one ~10-us launch) instead of
+// in the prologue of every consuming tile (12-16 strided loads per row in front of the tile's first barrier, repeated by each
+// of the row block's 3-16 column tiles).  LTR_STATS_COMB_MIN (lab; a huge value switches it off).  profiles/r05_rln_probe.txt
+inline int64_t stats_comb_min_rows() {
+  const char* e = getenv("LTR_STATS_COMB_MIN");        // (read per call: a test switches it inside one process)
+  return e ? atoll(e) : 8192;
+}
+
 // passes of at most this many rows get the small-batch split-K scratch (launch_gemm decides per launch)
 constexpr int64_t SPLITK_MAX_ROWS = 4800;
 
@@ -158,6 +166,8 @@ struct Workspace {
   AOp a2;
   void* stats1;
   void* stats2;
+  void* comb1;     // float2 [Tc]: (mean, rstd) of the rows behind stats1 / stats2, combined once per producer launch (large passes)
+  void* comb2;
   // GEMM head: compact last-token rows f32 [Nc, H] (only when the forward did not compact them), their operand
   // [Nc, H], the project_out result (operand or f32) [Nc, De], the padded logits f32 [Nc, lpad]
   float* head_rows;
@@ -188,6 +198,8 @@ Workspace carve(const ltr_model_desc& d, int64_t Tc, int64_t Nc, void* base, boo
     ws.a2 = AOp{a2, a2 ? a2 + Tc * H * 2 : nullptr};
     ws.stats1 = take((H / 64) * Tc * 8);
     ws.stats2 = take((H / 64) * Tc * 8);
+    ws.comb1 = take(Tc * 8);
+    ws.comb2 = take(Tc * 8);
   }
   if (head_lpad >= 0) {        // the GEMM head is in use (head_lpad = 0: project_out only)
     const size_t De = d.word_embed_proj_dim;
@@ -259,6 +271,7 @@ struct ChunkRun {
   const int wd, H, F, De, Tc, nreq;
   int nl = 0;
   bool fold = false, ln1_folded = false;
+  bool comb1_valid = false, comb2_valid = false;   // ws.comb1 / comb2 hold the combined statistics of the current stats1 / stats2
   // rows / buffers of the part of a layer after attention: all Tc token rows, except in the
   // last layer of a scoring call where only the nreq last-token rows are carried on (below)
   int Mr;
@@ -339,6 +352,7 @@ int ChunkRun::layer(const int L) {
         g.a = ws.a; g.w = m->last_kv_w; g.bias = qkv_b + H; g.out_split = kv; g.keep_lo_out = 1;
         g.M = Tc; g.N = 2 * H; g.K = H; g.a_slab = 1;
         if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L] + H; g.bias = m->fold_d_qkv[L] + H; g.ln_parts = H / 64; }
+        if (ln1_folded && comb1_valid) g.ln_stats_comb = ws.comb1;
         if ((rc = gemm(g))) return rc;
       }
       // The nreq last-token rows of the residual stream go to the tail of the qkv region (Tc * H * 4 bytes are
@@ -375,6 +389,7 @@ int ChunkRun::layer(const int L) {
         if (wd == LTR_W_F16 && !m->dbg_attn_valu) g.out_split = ws.qkv; else g.out_f32 = (float*)ws.qkv.hi;
         g.M = Tc; g.N = 3 * H; g.K = H; g.a_slab = wd == LTR_W_F16;   // A from LayerNorm / to_operand / the fold
         if (ln1_folded) { g.ln_stats_in = ws.stats1; g.ln_c = m->fold_c_qkv[L]; g.bias = m->fold_d_qkv[L]; g.ln_parts = H / 64; }
+        if (ln1_folded && comb1_valid) g.ln_stats_comb = ws.comb1;
         if ((rc = gemm(g))) return rc;
       }
       {
@@ -423,8 +438,14 @@ int ChunkRun::layer(const int L) {
       if (resid_pending) {   // residual = LN2 of layer L-1 applied to x, rebuilt in the epilogue
         g.rln_stats = ws.stats1; g.rln_gamma = (const float*)m->lw(L - 1, LTR_WL_LN2_W);
         g.rln_beta = (const float*)m->lw(L - 1, LTR_WL_LN2_B); g.rln_parts = H / 64;
+        if (comb1_valid) g.rln_stats_comb = ws.comb1;
       }
       if ((rc = gemm(g))) return rc;
+      comb2_valid = false;
+      if (fold_here && Mr >= stats_comb_min_rows()) {   // the pieces out_proj just wrote -> (mean, rstd) per row, once
+        if ((rc = launch_row_stats_combine(ws.stats2, H / 64, Mr, Mr, ws.comb2, s))) return rc;
+        comb2_valid = true;
+      }
     }
     if (!d.pre_ln && !fold_here) {   // 350m: LN after the residual add; h and its operand copy
       rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN1_W), (const float*)m->lw(L, LTR_WL_LN1_B), hb, ab);
@@ -440,6 +461,7 @@ int ChunkRun::layer(const int L) {
       g.a = fold_here ? ws.a2 : ab; g.w = m->gemm_lw(L, LTR_WL_FC1_W); g.bias = (const float*)m->lw(L, LTR_WL_FC1_B);
       g.out_split = fb; g.relu = 1; g.M = Mr; g.N = F; g.K = H; g.a_slab = g.out_slab = wd == LTR_W_F16;
       if (fold_here) { g.ln_stats_in = ws.stats2; g.ln_c = m->fold_c_fc1[L]; g.bias = m->fold_d_fc1[L]; g.ln_parts = H / 64; }
+      if (fold_here && comb2_valid) g.ln_stats_comb = ws.comb2;
       if ((rc = gemm(g))) return rc;
     }
     // the LayerNorm that follows this residual add rides on fc2: pre-LN blocks the NEXT layer's LN1 (also into the pruned
@@ -458,8 +480,14 @@ int ChunkRun::layer(const int L) {
       if (!d.pre_ln && fold_here) {   // residual = LN1 of this layer applied to out_proj's x
         g.rln_stats = ws.stats2; g.rln_gamma = (const float*)m->lw(L, LTR_WL_LN1_W);
         g.rln_beta = (const float*)m->lw(L, LTR_WL_LN1_B); g.rln_parts = H / 64;
+        if (comb2_valid) g.rln_stats_comb = ws.comb2;
       }
       if ((rc = gemm(g))) return rc;
+      comb1_valid = false;
+      if (ln1_folded && Mr >= stats_comb_min_rows()) {   // the pieces fc2 just wrote (for the next layer's QKV / out_proj), once
+        if ((rc = launch_row_stats_combine(ws.stats1, H / 64, Mr, Mr, ws.comb1, s))) return rc;
+        comb1_valid = true;
+      }
     }
     if (!d.pre_ln && !ln1_folded) {
       rc = lnorm(Mr, hb, (const float*)m->lw(L, LTR_WL_LN2_W), (const float*)m->lw(L, LTR_WL_LN2_B), hb, ab);

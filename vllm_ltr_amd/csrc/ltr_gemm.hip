@@ -90,6 +90,10 @@ struct Epilogue {
   // LTR_F_ONE_PASS: one_pass - the small-batch kernels skip the lo MFMA pass (the large-tile kernel has a template
   // instance without the lo stream); no_lo_out - the lo planes of out_hi / ln_hi's twins are not stored
   int one_pass, no_lo_out;
+  // (mean, rstd) per row, combined once per launch by row_stats_combine_kernel (GemmArgs::ln_stats_comb / rln_stats_comb);
+  // null: the tile combines the pieces itself
+  const float2* stats_comb;
+  const float2* r_stats_comb;
 };
 
 // LNS rides on the consumer arithmetic v = (acc - mean c_n) rstd with mean = 0, c_n = 0, rstd = the output scale
@@ -233,6 +237,34 @@ __device__ __forceinline__ float2 combine_row_stats(const float2* __restrict__ s
   const float mean = s0.x + s1 / np_;
   const float m2 = sm + 64.f * fmaxf(s2 - s1 * s1 / np_, 0.f);
   return make_float2(mean, rsqrtf(m2 / (64.f * np_) + LN_EPS) * out_scale);
+}
+
+// (mean, rstd [/ scale]) of one row for a tile's prologue: from the per-launch combined array when there is one.
+// The array's (mean, rstd) arrives as ONE 64-bit register; its components go through own_reg before anybody multiplies with
+// them: as the high half of that register, rstd is read through op_sel by the packed-f32 instructions hipcc makes of the
+// epilogue arithmetic, and the form it picked for splitk_epilogue_kernel<*, true> (v_pk_mul_f32 ... op_sel:[0,1]) is the one
+// that computes wrong values in lanes 48-63 beside a library fp16 GEMM - round 5's "concurrency-dependent wrong scores"
+// (profiles/r06_rln_fault.txt; isa_lint.py keeps the form out of the library).  LTR_RLN_FAULT_SHAPE rebuilds round 5's
+// expression for the reproducer (diag/rln_fault.hip); never in the library.
+template <bool RLN>
+__device__ __forceinline__ float2 tile_row_stat(const Epilogue& ep, int row) {
+#ifdef LTR_RLN_FAULT_SHAPE
+  if (RLN) return ep.r_stats_comb ? ep.r_stats_comb[row] : combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f);
+#else
+  if (RLN) {
+    if (!ep.r_stats_comb) return combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f);
+    const float2 st = ep.r_stats_comb[row];
+    return make_float2(own_reg(st.x), own_reg(st.y));
+  }
+#endif
+  if (ep.stats_comb) { const float2 st = ep.stats_comb[row]; return make_float2(own_reg(st.x), own_reg(st.y * (1.f / LN_FOLD_SCALE))); }
+  return combine_row_stats(ep.stats_in + row, ep.n_part, ep.ldm, 1.f / LN_FOLD_SCALE);
+}
+
+__global__ void __launch_bounds__(256) row_stats_combine_kernel(const float2* __restrict__ parts, int n_part, int ldm, int rows,
+                                                                float2* __restrict__ out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) out[r] = combine_row_stats(parts + r, n_part, ldm, 1.f);
 }
 
 // One (row, 8 columns) piece of the epilogue, shared by the large-tile and the small-tile kernel: x = accumulator
@@ -436,9 +468,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
   issue(0, 0);
   if ((LNM == LNC || RLN) && tid < BM) {
     const int row = min(m0 + tid, M - 1);
-    reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] =
-        RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f)
-            : combine_row_stats(ep.stats_in + row, ep.n_part, ep.ldm, 1.f / LN_FOLD_SCALE);
+    reinterpret_cast<float2*>(smem + 2 * STAGE)[tid] = tile_row_stat<RLN>(ep, row);
   }
   for (int kt = 0; kt < nk; ++kt) {
 #ifdef LTR_GEMM_TIMELINE
@@ -515,8 +545,8 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
     bias_a = *reinterpret_cast<const float4*>(ep.bias + ccol);
     bias_b = *reinterpret_cast<const float4*>(ep.bias + ccol_b);
   }
-  float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;      // LNP: gamma * scale; LNC: c_n
-  if ((LNM == LNP || LNM == LNC) && !RLN && ccol < N) {                // (RLN instances fetch it in their second sweep)
+    float4 lnv_a = make_float4(0.f, 0.f, 0.f, 0.f), lnv_b = lnv_a;      // LNP: gamma * scale; LNC: c_n
+  if ((LNM == LNP || LNM == LNC) && !RLN && ccol < N) {              // (RLN instances fetch it in their second sweep)
     const float* src = LNM == LNP ? ep.ln_gamma : ep.ln_c;
     lnv_a = *reinterpret_cast<const float4*>(src + ccol);
     lnv_b = *reinterpret_cast<const float4*>(src + ccol_b);
@@ -627,7 +657,7 @@ __global__ void __launch_bounds__(512, 4) gemm_f16s_kernel(
         if (LNM == LNC || RLN) st2 = reinterpret_cast<const float2*>(smem + 2 * STAGE)[gr[it] - m0];
         if (LNM == LNS) st2 = out_scale_stat(ep);
         epilogue_piece<LNM, RLN>(ep, va[it], vb[it], ra[it], rb[it], bias_a, bias_b, lnv_a, lnv_b, st2, st2, gr[it], ccol,
-                                 ccol_b, o[it], ep.ldm, lane, tn * 4 + wc);
+                                   ccol_b, o[it], ep.ldm, lane, tn * 4 + wc);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -783,8 +813,7 @@ __global__ void __launch_bounds__((SmallCfg<BM_, BN_, WM_, WN_, SL_, SSTAGES>::N
     if (st < nst) issue(st, st);
   if ((LNM == LNC || RLN) && tid < BM_) {     // (mean, M2) pieces of the row -> (mean, rstd [/ scale]); see the large-tile kernel
     const int row = min(m0 + tid, M - 1);
-    s_stat[tid] = RLN ? combine_row_stats(ep.r_stats + row, ep.r_parts, ep.ldm, 1.f)
-                      : combine_row_stats(ep.stats_in + row, ep.n_part, ep.ldm, 1.f / LN_FOLD_SCALE);
+    s_stat[tid] = tile_row_stat<RLN>(ep, row);
   }
   for (int kt = 0; kt < nst; ++kt) {
     // stage kt has landed once at most the younger stages' pieces (NP per stage and wave) are outstanding
@@ -953,7 +982,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
     lnv_b.x *= LN_FOLD_SCALE; lnv_b.y *= LN_FOLD_SCALE; lnv_b.z *= LN_FOLD_SCALE; lnv_b.w *= LN_FOLD_SCALE;
   }
   float2 rst = make_float2(0.f, 0.f);
-  if (RLN) rst = combine_row_stats(ep.r_stats + grow, ep.r_parts, ep.ldm, 1.f);
+  if (RLN) rst = tile_row_stat<true>(ep, grow);
   epilogue_piece<LNM, RLN>(ep, va, vb, ra, rb, bias_a, bias_b, lnv_a, lnv_b, rst, rst, grow, ccol, ccol_b, o, ep.ldm, lane, pc);
 }
 
@@ -1086,6 +1115,13 @@ int launch_ln_fold_coeff(const void* w_f16, const float* gamma, const float* bet
   return LTR_OK;
 }
 
+int launch_row_stats_combine(const void* parts, int n_part, int ldm, int rows, void* out, hipStream_t s) {
+  if (rows <= 0) return LTR_OK;
+  row_stats_combine_kernel<<<(rows + 255) / 256, 256, 0, s>>>((const float2*)parts, n_part, ldm, rows, (float2*)out);
+  LTR_LAUNCH_CHECK();
+  return LTR_OK;
+}
+
 int launch_pack_weight(const void* src, void* dst, int N, int K, hipStream_t s, int n_src) {
   if (K % BK16) { set_error("pack_weight: K=%d must be a multiple of %d", K, BK16); return LTR_E_INVAL; }
   const size_t pieces = (size_t)N * K / 8;
@@ -1159,7 +1195,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, Mend, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
               g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts, g.osc_a, g.osc_b,
-              g.row0, ldm, g.one_pass, g.no_lo_out};
+              g.row0, ldm, g.one_pass, g.no_lo_out, (const float2*)g.ln_stats_comb, (const float2*)g.rln_stats_comb};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : (g.osc_a ? LNS : LN_NONE));
   if (g.osc_a && (wdtype != LTR_W_F16 || !g.osc_b || g.ln_gamma || g.ln_stats_in || g.rln_stats)) {
     set_error("gemm: scaled operands (osc_a / osc_b) need F16 mode, both scales and no LayerNorm fold");

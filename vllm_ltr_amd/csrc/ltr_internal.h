@@ -97,6 +97,12 @@ struct GemmArgs {
   int ldm = 0;
   // LTR_F_ONE_PASS (F16 mode): multiply the hi plane of A only (the lo plane is neither streamed nor multiplied);
   // no_lo_out: do not store the lo planes of out_split / ln_out either (their only reader is another one-pass GEMM)
+  // Row statistics combined ONCE per launch instead of in every tile's prologue (launch_row_stats_combine): float2 [ldm]
+  // (mean, rstd) of the rows of A (consumer: ln_stats_in stays set and selects the epilogue) / of `resid` (rln_stats likewise).
+  // Round 5: a [128 rows] x [12-16 pieces] gather in front of the first barrier of each of a row block's 3-16 column tiles is
+  // redundant work on the critical path of every tile; large passes combine once (ltr_api.hip ChunkRun::layer).
+  const void* ln_stats_comb = nullptr;
+  const void* rln_stats_comb = nullptr;
   int one_pass = 0;
   int no_lo_out = 0;
   int keep_lo_out = 0;   // (caller's note to ChunkRun::gemm: this output's lo plane has a reader that is not a one-pass kernel)
@@ -104,6 +110,8 @@ struct GemmArgs {
 
 // launchers (each in its own .hip file)
 int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s);
+// out[r] = (mean, rstd) of row r from its n_part 64-column pieces (mean, M2), parts = float2 [n_part][ldm]; rows [0, rows)
+int launch_row_stats_combine(const void* parts, int n_part, int ldm, int rows, void* out, hipStream_t s);
 // F16 mode: -1 = this shape runs on the 128 x 256 kernel (gemm_f16s_kernel), 0 / 1 = on a small-batch kernel (profiling)
 int gemm_small_config(const GemmArgs& g);
 // n_src < N: the source has n_src rows, the image is padded with zero rows up to N (N a multiple of 64 for launch_gemm)
@@ -193,6 +201,17 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32-l
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// A value in a 32-bit register of its own.  hipcc vectorises neighbouring f32 operations into packed instructions
+// (v_pk_mul_f32 ...) and, when an operand is the HIGH half of a 64-bit register (the y of a float2 that was loaded or merged as
+// one value), reads it through op_sel.  One of those forms - op_sel:[0,1]: src1's lo lane from the high register - computes a
+// wrong lo half in lanes 48-63 on MI355X while a library fp16 GEMM shares the CU (profiles/r06_rln_fault.txt; the build's ISA
+// lint, isa_lint.py, rejects it).  Passing the scalar through here first makes the compiler broadcast it from the low half of
+// a pair instead (op_sel_hi forms, which are correct).
+__device__ __forceinline__ float own_reg(float v) {
+  asm volatile("" : "+v"(v));
   return v;
 }
 

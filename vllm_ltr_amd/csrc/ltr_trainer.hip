@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x
   const float rstd = rsqrtf(wave_sum(q) / (float)H + LN_EPS);
   float sg = 0.f, sgx = 0.f;
   for (int c = lane; c < H; c += 64) {
-    const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+    const float xh = own_reg((xr[c] - mean) * rstd), g = dr[c] * gamma[c];     // (own_reg: isa_lint.py)
     sg += g; sgx += g * xh;
   }
   const float mg = wave_sum(sg) / (float)H, mgx = wave_sum(sgx) / (float)H;
