@@ -174,19 +174,29 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #ifndef LTR_EPI_STORE
 #define LTR_EPI_STORE 1
 #endif
+// LTR_EPI_NOPS=1 (A/B knob) puts 16 wait states in front of the asm stores, as rounds 2-5 shipped them: an experimental epilogue
+// of round 2 "stored stale registers in one lane of 16" and the s_nops cured it.  That epilogue is long gone and the cause was
+// never found; round 6 built the library without them: gemm_check clean at every shape / tile configuration / K split, the
+// parity suite and the busy-GPU soak green (profiles/r06_rln_fault.txt, end) - they guard nothing in this tree and are off.
+#ifndef LTR_EPI_NOPS
+#define LTR_EPI_NOPS 0
+#endif
+#if LTR_EPI_NOPS
+#define LTR_EPI_PRE "s_nop 7\n\ts_nop 7\n\t"
+#else
+#define LTR_EPI_PRE ""
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void epi_store16(void* p, const void* v) {
   const u32x4 d = *reinterpret_cast<const u32x4*>(v);
 #if LTR_EPI_STORE == 1
-  // Inline asm (the compiler's own __builtin_nontemporal_store costs out_proj 12 %: 610 vs 545 us per 196k-token launch,
-  // diag/gemm_bench.hip) behind 16 wait states: the hazard recogniser does not look inside asm statements, and in an
-  // experimental epilogue a global_store placed right behind the VALU / LDS-permute ops that built its operands
-  // stored stale registers in one lane of 16 (diag/gemm_check.hip); the s_nops cured it and cost nothing measurable.
-  asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+  // Inline asm: the compiler's own __builtin_nontemporal_store costs out_proj 12 % (610 vs 545 us per 196k-token launch,
+  // diag/gemm_bench.hip).  The operands are ordinary "v" inputs, so the compiler's waitcnt / hazard passes see what feeds them.
+  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 2
-  asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 3
-  asm volatile("s_nop 7\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 5
   __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(p));
 #else
