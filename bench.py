@@ -229,7 +229,9 @@ class ColdCall:
         return float(t.item()), sorted(a.elapsed_time(b) for a, b in ev)
 
     def release(self):
-        del self.ids_d, self.cu_d, self.queue, self.need_tokens, self.need_seqs, self.perm
+        for a in ("ids_d", "cu_d", "queue", "need_tokens", "need_seqs", "perm"):
+            if hasattr(self, a):
+                delattr(self, a)
 
 
 def run_trace(args, spec, ckpt, dev):
@@ -334,6 +336,7 @@ def main():
                     help="steady calls to time outside the timed region: k new requests scored + the whole queue re-ranked "
                          "(SURVEY 8d 'steady'); comma list, '0' = none")
     ap.add_argument("--no-strong", action="store_true", help="skip the 65,536-request strong-scaling point")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (OPT-350m, 8k lmsys queue) of the default run")
     ap.add_argument("--no-class-head", action="store_true",
                     help="skip the class-mode head measurement (8,192 requests x 8,192 labels, kernels.class_head)")
     ap.add_argument("--sweep", "--scale-table", dest="sweep", action="store_true",
@@ -556,6 +559,52 @@ def main():
                           note="LayerNorm / project_out of the last-token rows + logits GEMM + argmax, per call")
         sc_c.close(); del sc_c, ids_c, out_c
 
+    # ---- BASELINE config 3 in the driver's own record: OPT-350m predictor, 8,192-request LMSYS-like queue, one
+    # GPU - one warm-up, two timed cold calls (profiler off), one more with the event profiler for the kernel classes.  Only in
+    # the default run (the headline workload on one GPU); `--model 350m --profile lmsys` is the full-length run of the same thing.
+    config3 = None
+    if (rank == 0 and world == 1 and not args.no_config3 and args.weight_dtype == "f16" and not args.sweep and not strong
+            and (args.model, args.profile, args.queue) == ("125m", "sharegpt", 8192)):
+        call.release()
+        spec3 = OPTSpec.opt_350m()
+        ck3 = seeded_checkpoint(spec3, 0)
+        sc3 = HipOPTScorer(spec3, ck3, str(dev), "f16")
+        c3 = ColdCall(spec3, sc3, dev, None, 1, 0, 8192, "lmsys", args.min_shard_tokens, args.starv, args.period,
+                      timeout_s=args.collective_timeout)
+        sc3.profile(False)
+        el3, _ = c3.timed(2, 1)
+        sc3.profile(True); sc3.profile_read(reset=True)
+        c3.timed(1, 0)
+        p3 = sc3.profile_read(reset=True)
+        sc3.profile(False)
+        T3 = int(c3.cu[-1])
+        lin3, att3 = model_flops(spec3, c3.lens)
+        g3 = p3["gemm"]
+        tf3 = g3["work"] / (g3["ms"] * 1e-3) / 1e12 if g3["ms"] > 0 else 0.0
+        comp3 = compulsory_bytes(spec3, T3, max(1, -(-T3 // 196608)))
+        traffic3, tsrc3 = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic.350m_lmsys_8192.json")))
+            tsrc3 = tj.get("source")
+            if tsrc3 and tsrc3.get("kernel_sha16") == kernel_sources_sha16() and tsrc3.get("workload") == "350m/lmsys/8192":
+                traffic3 = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        config3 = {
+            "workload": "OPT-350m predictor, 8192-request synthetic queue (lmsys length profile), cold ranker call, 1 GPU (BASELINE configs[2])",
+            "tokens_total": T3, "steps": 2, "warmup": 1, "value": 8192 * 2 / el3, "unit": "requests/s", "ms_per_step": el3 / 2 * 1e3,
+            "model_tflop_per_step": (lin3 + att3) / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16s_kernel", "achieved": tf3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf3 / PEAK_F16_MFMA_TFLOPS, "hw_frac": 2 * tf3 / PEAK_F16_MFMA_TFLOPS, "launches_per_step": g3["launches"],
+                         "avg_launch_ms": g3["ms"] / max(g3["launches"], 1), "traffic": traffic3, "compulsory_bytes": comp3,
+                         "traffic_ratio": traffic3 * g3["launches"] / comp3 if traffic3 else None,
+                         "traffic_source": tsrc3 if traffic3 is not None else {"stale": True, "file": tsrc3,
+                                                                               "current_kernel_sha16": kernel_sources_sha16()},
+                         "measured": "one more cold call with HIP events around every launch (profiler off in the two timed calls)"},
+            "kernels": {k: dict(ms_per_step=v["ms"], launches_per_step=v["launches"]) for k, v in p3.items() if v["launches"]},
+        }
+        c3.release(); sc3.close(); del c3, sc3, ck3
+
     if rank == 0:
         lin, att = model_flops(spec, lens[my_r0:my_r1])        # this rank's shard: what its profiler timed
         kernels, roof = {}, None
@@ -679,6 +728,7 @@ def main():
             # north_star: "ranker calls/sec on synthetic 1k-64k-request queues": cold calls on FIXED queues at this N
             # (with the headline = the 8k point and strong_scaling = the 64k point: five queue sizes)
             "scale_table": scale_pts,
+            "config3": config3,
             "model_tflop_per_step": (lin + att) / 1e12,
             "input_distribution": ("driver-broadcast: only rank 0 holds the queue; header broadcast + one per-rank scatter of "
                                    "(cu_seqlens slice, token ids) inside every timed step" if args.driver_broadcast and world > 1
