@@ -157,7 +157,7 @@ class ColdCall:
     """One global queue of ``n_total`` requests, resident on every rank, and its cold ranker call."""
 
     def __init__(self, spec, scorer, dev, dist, world, rank, n_total, profile, min_shard_tokens, starv, period, seed=0,
-                 timeout_s=None, driver_mode=False):
+                 timeout_s=None, driver_mode=False, sharded=None):
         from vllm_ltr_amd.distributed import ShardedScorer, shard_bounds
         from vllm_ltr_amd.rank import DeviceQueue
         self.scorer, self.dev, self.dist, self.world, self.rank, self.n_total = scorer, dev, dist, world, rank, n_total
@@ -168,7 +168,10 @@ class ColdCall:
         self.passive = self.driver_mode and rank != 0
         self.ids_d = None if self.passive else torch.from_numpy(self.ids).to(dev)
         self.cu_d = None if self.passive else torch.from_numpy(self.cu).to(dev)
-        self.sharded = ShardedScorer(scorer, dev, min_tokens_to_shard=min_shard_tokens, timeout_s=timeout_s, driver_rank=0) if world > 1 else None
+        # (one wrapper for the whole run when the caller has one: its header side channel is a process group of its own)
+        self.sharded = sharded if sharded is not None else (
+            ShardedScorer(scorer, dev, min_tokens_to_shard=min_shard_tokens, timeout_s=timeout_s, driver_rank=0,
+                          control="auto" if self.driver_mode else None) if world > 1 else None)
         self.is_sharded = bool(self.sharded is not None and self.sharded.shards(n_total, int(self.cu[-1])))
         self.bounds = shard_bounds(self.cu, world) if self.is_sharded else [(0, n_total)] + [(n_total, n_total)] * (world - 1)
         self.r0, self.r1 = self.bounds[rank]
@@ -400,6 +403,44 @@ def main():
 
     from vllm_ltr_amd.scorer import HipOPTScorer
 
+    # ---- preflight of the N-rank run (the first real RCCL run should say what it found before it times
+    # anything): library version, every rank's device, one 4-byte all-gather round trip.  Rank 0 prints it on stderr at once
+    # (so that it survives a later hang) and the final line carries it.
+    preflight = None
+    if dist is not None:
+        pf = {"backend": backend, "ranks": world}
+        try:
+            pf["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception as e:      # noqa: BLE001
+            pf["rccl_version"] = f"unavailable ({type(e).__name__})"
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            mine = dict(rank=rank, local_rank=local_rank, device=props.name, cus=props.multi_processor_count,
+                        pci=getattr(props, "pci_bus_id", None), hbm_gb=round(props.total_memory / 2**30))
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            pf["devices"] = allr
+            on = backend == "nccl"
+            a = torch.zeros(1, dtype=torch.float32, device=dev if on else "cpu")
+            g = torch.zeros(world, dtype=torch.float32, device=dev if on else "cpu")
+            ts = []
+            for _ in range(25):
+                if on:
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dist.all_gather_into_tensor(g, a)
+                if on:
+                    torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e6)
+            pf["all_gather_4B_us_p50"] = sorted(ts[5:])[len(ts[5:]) // 2]
+            pf["ok"] = True
+        except Exception as e:      # noqa: BLE001 - say it and go on: the timed run will fail where the collective is needed
+            pf["ok"] = False
+            pf["error"] = f"{type(e).__name__}: {e}"[:300]
+        preflight = pf
+        if rank == 0:
+            print(json.dumps({"kind": "preflight", **pf}), file=sys.stderr, flush=True)
+
     spec = OPTSpec.opt_125m() if args.model == "125m" else OPTSpec.opt_350m()
     ckpt = seeded_checkpoint(spec, 0)
     if args.trace:
@@ -411,8 +452,13 @@ def main():
     strong = args.queue_total > 0
     n_total = args.queue_total if strong else args.queue * world
     n_local = n_total // world if strong else args.queue
+    shared = None
+    if world > 1:
+        from vllm_ltr_amd.distributed import ShardedScorer
+        shared = ShardedScorer(scorer, dev, min_tokens_to_shard=args.min_shard_tokens, timeout_s=args.collective_timeout, driver_rank=0,
+                               control="auto" if args.driver_broadcast else None)
     mk = lambda n: ColdCall(spec, scorer, dev, dist, world, rank, n, args.profile, args.min_shard_tokens, args.starv, args.period,
-                            timeout_s=args.collective_timeout, driver_mode=args.driver_broadcast)
+                            timeout_s=args.collective_timeout, driver_mode=args.driver_broadcast, sharded=shared)
     f16 = args.weight_dtype in ("f16", "f16-1pass")        # both run the fp16-weight kernels
     one_pass = args.weight_dtype == "f16-1pass"
 
@@ -730,9 +776,12 @@ def main():
             "scale_table": scale_pts,
             "config3": config3,
             "model_tflop_per_step": (lin + att) / 1e12,
-            "input_distribution": ("driver-broadcast: only rank 0 holds the queue; header broadcast + one per-rank scatter of "
-                                   "(cu_seqlens slice, token ids) inside every timed step" if args.driver_broadcast and world > 1
+            "input_distribution": ((f"driver-broadcast: only rank 0 holds the queue; header ({shared.header_channel}) + "
+                                    + ("one per-rank scatter of (cu_seqlens slice, token ids)" if shared.distribution == "scatter" else
+                                       f"ONE broadcast of the whole (cu_seqlens, token ids) payload [fallback: {shared.distribution_note}]")
+                                    + " inside every timed step") if args.driver_broadcast and world > 1
                                    else "resident: every rank holds the whole queue before the timed region (SPMD)"),
+            "preflight": preflight,
         }
         if one_pass:
             out["metric"] = ("requests ranked/sec, ONE fp16 MFMA pass per product (the reference's fp16 GPU arithmetic, ~2e-3 from "

@@ -258,3 +258,106 @@ def test_shard_decision_is_a_token_rule_by_default():
     assert sh.shards(64, 100) and not sh.shards(63, 10**9)
     sh.world = 1
     assert not sh.shards(10**6, 10**9)
+
+
+# ---- round 6: the hardened driver / workers mode ----------------------------------------
+def _worker_hardened(rank, world, port, q, scenario):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if scenario == "scatter_fails":
+        os.environ["LTR_DIST_SCATTER_FAIL"] = "1"
+    import datetime
+    import time
+    import torch.distributed as dist
+    # a SHORT process-group timeout on purpose: an idle worker must not depend on it
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=4))
+    try:
+        torch.set_num_threads(1)
+        from oracle.opt_scorer import OracleOPTScorer
+        from util import synthetic_batch
+        from vllm_ltr_amd.distributed import ShardedScorer
+        from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+        spec = OPTSpec.tiny_pre_ln()
+        orc = OracleOPTScorer(spec, seeded_checkpoint(spec, 3))
+        log = []
+        driver = 0
+        sc = _CpuDeviceScorer(orc, log)
+        if scenario == "driver_raises" and rank == driver:
+            real = sc.score_device
+            state = {"n": 0}
+
+            def flaky(*a, **kw):
+                state["n"] += 1
+                if state["n"] == 1:
+                    raise MemoryError("out of workspace in the driver's own shard")
+                return real(*a, **kw)
+            sc.score_device = flaky
+        sh = ShardedScorer(sc, "cpu", min_requests_to_shard=16, timeout_s=30.0, driver_rank=driver, control=True)
+        if rank != driver:
+            served = sh.serve()
+            q.put((rank, "worker", served, sh.distribution, sh.header_channel))
+            return
+        out = {"header_channel": sh.header_channel}
+        try:
+            r = np.random.RandomState(5)
+            if scenario == "idle":
+                time.sleep(7.0)                                  # longer than the process group's 4-s timeout: the workers idle in serve()
+            for name, n in (("a", 64), ("b", 41)):
+                ids, cu = synthetic_batch(spec, r.randint(1, 40, n).tolist(), 2 + n)
+                ids_d, cu_d = torch.from_numpy(ids), torch.from_numpy(cu)
+                try:
+                    got = sh.score_from_driver(ids_d, cu_d, cu).numpy().copy()
+                    code = sh.agree_status(0) if sh.last_call_collective else -1
+                    out[name] = (bool(np.abs(got - orc.score(ids, cu)).max() < 1e-6), code, sh.distribution)
+                except MemoryError as e:
+                    out[name] = ("raised", str(e), sh.last_call_collective)
+        finally:
+            sh.stop_workers()
+        q.put((rank, "driver", out, sh.distribution, sh.distribution_note))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_hardened(scenario, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hardened, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return next(r for r in res if r[1] == "driver"), [r for r in res if r[1] == "worker"]
+
+
+def test_idle_workers_outlive_the_process_group_timeout():
+    """a worker that waits for the next header must not sit in a collective of the data group - that wait is
+    bounded by the group's own timeout (4 s here; 10 min by default on RCCL, where a broadcast kernel also spins on the GPU).  The
+    header travels on a gloo side channel with a year-long timeout: 7 s of idling, then two sharded calls, all served."""
+    drv, wrk = _run_hardened("idle")
+    out = drv[2]
+    assert out["header_channel"] == "gloo side channel"
+    assert out["a"] == (True, 0, "scatter") and out["b"] == (True, 0, "scatter")
+    assert wrk[0][2] == 2 and wrk[0][4] == "gloo side channel"
+
+
+def test_scatter_failure_falls_back_to_one_broadcast():
+    """if `dist.scatter` raises on the backend (simulated: LTR_DIST_SCATTER_FAIL=1 on every rank), the SAME call
+    goes on with one broadcast of the whole payload, the scores are the unsharded ones, and the mode sticks (and says why)."""
+    drv, wrk = _run_hardened("scatter_fails")
+    out = drv[2]
+    assert out["a"] == (True, 0, "broadcast") and out["b"] == (True, 0, "broadcast")
+    assert drv[3] == "broadcast" and "simulated" in drv[4]
+    assert wrk[0][2] == 2 and wrk[0][3] == "broadcast"
+
+
+def test_driver_failure_inside_a_call_does_not_strand_the_workers():
+    """the driver's own shard raises after header and payload have gone out.  The driver still feeds the
+    all-gather and the status agreement, then re-raises; the worker serves that call and the next one."""
+    drv, wrk = _run_hardened("driver_raises")
+    out = drv[2]
+    assert out["a"][0] == "raised" and "workspace" in out["a"][1] and out["a"][2] is False
+    assert out["b"] == (True, 0, "scatter")
+    assert wrk[0][2] == 2

@@ -429,3 +429,86 @@ def test_plain_bench_gpus_1_on_rccl_world_1_with_scale_table():
     assert r["compulsory_bytes"] > 0 and r["mfma_only_floor_ms"] > 0 and "traffic_note" in r
     assert table["kind"] == "scale_table" and [p["queue_total"] for p in table["points"]] == [256, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
     assert all(p["calls_per_s"] > 0 and 0 < p["mfma_frac"] < 1 and 0 < p["hbm_frac_compulsory"] < 1 for p in table["points"])
+
+
+# ---- round 6: a world-8 dry run of the driver / workers mode on one device that takes BOTH payload forms ------
+def _worker_world8_payload_forms(rank, world, port, q, form):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if form == "scatter_fails":
+        os.environ["LTR_DIST_SCATTER_FAIL"] = "1"
+    elif form == "broadcast":
+        os.environ["LTR_DIST_PAYLOAD"] = "broadcast"
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from util import bench_lengths, synthetic_batch
+        from vllm_ltr_amd.distributed import ShardedScorer
+        from vllm_ltr_amd.opt_spec import OPTSpec, seeded_checkpoint
+        from vllm_ltr_amd.scorer import HipOPTScorer
+        spec = OPTSpec.tiny_pre_ln()
+        sc = HipOPTScorer(spec, seeded_checkpoint(spec, 3), "cuda:0", "f16")
+        dev = torch.device("cuda:0")
+        sh = ShardedScorer(sc, dev, min_requests_to_shard=64, timeout_s=300.0, driver_rank=0, control=True)
+        if rank != 0:
+            q.put((rank, "worker", sh.serve(), sh.distribution))
+            return
+        res = {"header_channel": sh.header_channel}
+        try:
+            for name, n, seed in (("first", 900, 5), ("second", 333, 6)):
+                lens = bench_lengths(n, seed=seed, mu=24.0).clip(1, 150)
+                ids, cu = synthetic_batch(spec, lens.tolist(), seed)
+                ids_d, cu_d = torch.from_numpy(ids).to(dev), torch.from_numpy(cu).to(dev)
+                single = sc.score_device(ids_d, cu_d, cu).cpu().numpy()
+                got = sh.score_from_driver(ids_d, cu_d, cu).cpu().numpy()
+                code = sh.agree_status(0) if sh.last_call_collective else -1
+                res[name] = (float(np.abs(got - single).max() / max(1.0, np.abs(single).max())), code, sh.distribution)
+        finally:
+            sh.stop_workers()
+        q.put((rank, "driver", res, sh.distribution_note))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("form", ["scatter", "scatter_fails", "broadcast"])
+def test_world8_driver_mode_takes_both_payload_forms(form):
+    """Eight processes on the one device (gloo data group + the gloo header side channel): the driver's batch reaches the seven
+    workers by ONE scatter of per-rank shards, or - when `dist.scatter` raises (simulated) / LTR_DIST_PAYLOAD=broadcast - by one
+    broadcast of the whole payload; either way the gathered scores equal the one-process scores (2e-6) and every worker served
+    both calls."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_world8_payload_forms, args=(r, world, port, q, form)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    drv = next(r for r in res if r[1] == "driver")
+    out = drv[2]
+    want = "scatter" if form == "scatter" else "broadcast"
+    assert out["header_channel"] == "gloo side channel"
+    for name in ("first", "second"):
+        err, code, dist_form = out[name]
+        assert err <= 2e-6 and code == 0 and dist_form == want, (name, out[name])
+    assert all(r[2] == 2 and r[3] == want for r in res if r[1] == "worker")
+    if form == "scatter_fails":
+        assert "simulated" in drv[3]
+
+
+def test_bench_preflight_and_payload_fallback_in_the_line():
+    """`bench.py --gpus 2 --driver-broadcast` with a failing scatter: the run goes on over the broadcast form and the line says so;
+    every N-rank line carries the preflight record (backend, every rank's device, a 4-byte all-gather round trip)."""
+    lines = _bench_line(["--gpus", "2", "--steps", "1", "--warmup", "1", "--queue", "2048", "--no-cpu-baseline", "--no-unfused",
+                         "--no-strong", "--no-scale-points", "--no-class-head", "--no-config3", "--steady-new", "0", "--driver-broadcast"],
+                        dict(LTR_BENCH_ONE_DEVICE="1", LTR_BENCH_BACKEND="gloo", LTR_DIST_SCATTER_FAIL="1"))
+    out = lines[-1]
+    assert "ONE broadcast of the whole" in out["input_distribution"] and "simulated" in out["input_distribution"]
+    pf = out["preflight"]
+    assert pf["ok"] and pf["ranks"] == 2 and len(pf["devices"]) == 2 and pf["all_gather_4B_us_p50"] > 0
+    assert out["value"] > 0
