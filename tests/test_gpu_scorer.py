@@ -918,3 +918,20 @@ def test_row_statistics_combined_once_per_launch_are_invisible(dev, model, monke
 
 def _first(ids, cu, n):
     return ids[:cu[n]], cu[:n + 1]
+
+
+@pytest.mark.parametrize("variant", ["st", "sharded", "bin", "rank1", "fp32"])
+def test_verify_checkpoint_tool_on_hf_written_directories(variant):
+    """tests/tools/verify_checkpoint.py - the one command for `LLM-ltr/OPT-Predictors` (README.md:26) once somebody has network
+    access: an HF directory through load_hf_checkpoint, 64 prompts through the oracle and through MI355XRanker, max|d| / discordant
+    pairs / range_fallbacks printed, exit code 0 inside north_star's 1e-4."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "verify_checkpoint.py"),
+                        os.path.join(GOLDEN, "hf_tiny", variant), "-n", "64"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    rec = json.loads(r.stdout[r.stdout.index("{"):])
+    assert rec["verdict"] == "PASS" and rec["max_abs_err"] <= 1e-4 and rec["range_fallbacks"] == 0
+    assert rec["tokens"] > 64 and "synthetic" in rec["prompts"]
