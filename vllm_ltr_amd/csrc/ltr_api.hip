@@ -544,6 +544,11 @@ int lane_probe(hipStream_t s, hipStream_t lane, hipEvent_t fork, hipEvent_t join
     return LTR_OK;
   };
   rc = run();
+  if (rc) {     // a failure between fork and join: the caller's stream must still not run ahead of what the lane was given
+    (void)hipEventRecord(join, lane);
+    (void)hipStreamWaitEvent(s, join, 0);
+    (void)hipGetLastError();
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
   return rc;
 }
@@ -976,7 +981,16 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     }
     std::unique_lock<std::mutex> lane_lock(h->lane_mu, std::defer_lock);
     if (r_mid > 0 && !lane_lock.try_lock()) r_mid = -1;
-    if (r_mid > 0) {                   // does the lane stream run beside THIS caller stream?  (probed once per stream)
+    Workspace wa{}, wb{};
+    if (r_mid > 0) {                   // the two halves' scratch must fit what the caller gave (checked BEFORE any probing)
+      const int tm_ = cu[r_mid];
+      wa = carve(d, tm_ - t0, r_mid - r0, workspace, h->ln_fold, head_mode(h));
+      wb = carve(d, t1 - tm_, r1 - r_mid, (char*)workspace + align_up(wa.bytes), h->ln_fold, head_mode(h));
+      if (align_up(wa.bytes) + wb.bytes > ws_bytes) { r_mid = -1; lane_lock.unlock(); }
+    }
+    if (r_mid > 0) {                   // does the lane stream run beside THIS caller stream?  (probed once per stream; ltr_lane_probe
+                                       // pre-probes a stream outside the scoring path.  The verdict is keyed by the stream HANDLE: a
+                                       // destroyed stream whose handle value is reused inherits it - worst case one lane where two would do)
       bool known = !h->lane_probe_on, ok = true;
       for (auto& e : h->lane_seen) if (e.first == s) { known = true; ok = e.second; }
       if (!known) {
@@ -989,9 +1003,7 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     }
     if (r_mid > 0) {
       const int tm_ = cu[r_mid];
-      Workspace wa = carve(d, tm_ - t0, r_mid - r0, workspace, h->ln_fold, head_mode(h));
-      Workspace wb = carve(d, t1 - tm_, r1 - r_mid, (char*)workspace + align_up(wa.bytes), h->ln_fold, head_mode(h));
-      if (align_up(wa.bytes) + wb.bytes <= ws_bytes) {
+      {
         hipStream_t s2 = h->lane_stream;
         LTR_HIP_CHECK(hipEventRecord(h->lane_fork, s));
         LTR_HIP_CHECK(hipStreamWaitEvent(s2, h->lane_fork, 0));

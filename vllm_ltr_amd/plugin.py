@@ -507,6 +507,10 @@ class MI355XRanker:
         if not getattr(self.scorer, "ln_fold", False):
             return
         twin = self.scorer.unfolded_twin()
+        # (the folded handle may live on in its creator's hands; its default scratch and THIS ranker's prescore scratch need not)
+        if self.prescore:
+            self._pre_stream.synchronize()
+        self.scorer.release_workspaces((self._pre_ws_key, self._pre_ws_key + "-graph"))
         self.scorer = twin
         if self._sharded is not None:
             self._sharded.scorer = twin

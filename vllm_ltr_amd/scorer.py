@@ -98,6 +98,7 @@ class HipOPTScorer:
         # torch issued on the same stream) and makes self.device current for its own launches
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), self._stream(), C.byref(self._h)), "ltr_create")
+        self.chunk_tokens = 0
         if chunk_tokens:
             self.set_chunk_tokens(chunk_tokens)
         self._ws: Optional[torch.Tensor] = None
@@ -116,6 +117,7 @@ class HipOPTScorer:
 
     def set_chunk_tokens(self, n: int):
         _lib.check(self.lib.ltr_set_chunk_tokens(self._h, int(n)), "ltr_set_chunk_tokens")
+        self.chunk_tokens = int(n)
         self._ws = None
 
     def _lane_flags(self) -> int:
@@ -143,7 +145,18 @@ class HipOPTScorer:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), self._stream(), C.byref(twin._h)), "ltr_create")
         twin._ws, twin._ws_by_key = None, {}
+        twin.chunk_tokens = 0
+        if getattr(self, "chunk_tokens", 0):              # (a handle configured with set_chunk_tokens keeps its pass size)
+            twin.set_chunk_tokens(self.chunk_tokens)
         return twin
+
+    def release_workspaces(self, keys=()) -> None:
+        """Drop the default-stream scoring scratch and the named side-stream scratches (re-grown on demand): what a ranker calls
+        on the handle it has just replaced by its unfolded twin, so that the scratch is not held twice while somebody else still
+        references the old handle.  (Other users' keyed scratches stay: they may be in flight on their own streams.)"""
+        self._ws = None
+        for k in keys:
+            self._ws_by_key.pop(k, None)
 
     def lane_probe(self):
         """(candidates ltr_create tried, us of one 20-us spin kernel on the current stream, us of one on each of the two
