@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LTR_ABI_VERSION 5
+#define LTR_ABI_VERSION 6
 
 enum {
   LTR_OK = 0,
@@ -60,14 +60,15 @@ typedef struct ltr_model_desc {
  *  LTR_F_NO_LN_FOLD  the GEMMs are fed the bounded LayerNorm OUTPUT by separate LayerNorm launches instead of the folded
  *                    operand x * gamma * 16 (which must stay inside fp16: LTR_E_RANGE).  The twin handle a caller falls back
  *                    to when ltr_status reports LTR_E_RANGE for a checkpoint with massive activations (plugin.py).
- *  LTR_F_NO_LANES    never run a call as two halves on two streams (see "Lanes" below).
+ *  LTR_F_NO_LANES, LTR_F_LANES_UNPROBED   accepted and ignored since ABI 6: rounds 4-5 ran mid-sized calls as two halves on two
+ *                    streams ("lanes"); measured again in round 6 (-3.8 % at k = 64 on one predictor, +8.5 % on the other,
+ *                    profiles/r06_lanes_after.txt) and removed with ltr_lane_calls / ltr_lane_probe.  A scoring call uses `stream` only.
  *  LTR_F_ONE_PASS    F16 mode with ONE fp16 MFMA pass per product, in the GEMMs and in the attention (q, k, v, p as plain
  *                    fp16): activations rounded to fp16 (the `lo` plane is neither loaded nor multiplied, and not stored
  *                    where every reader runs one pass), f32 accumulate - the arithmetic of the reference's own GPU path (fp16 model,
  *                    vllm/config.py:906-943; train/trainer.py:213-216).  Scores move by ~2e-3 against the fp32 predictor:
  *                    OUTSIDE the 1e-4 contract of the default mode; opt-in, reported as its own number by bench.py.
- *  LTR_F_LANES_UNPROBED  keep the first lane-stream candidate without the overlap probe (tests of the two-lane
- *                    arithmetic, which does not depend on whether the halves overlap; lab). */
+ */
 enum { LTR_F_NO_LN_FOLD = 1, LTR_F_NO_LANES = 2, LTR_F_ONE_PASS = 4, LTR_F_LANES_UNPROBED = 8 };
 
 /* Order of the device pointers handed to ltr_create (HF tensor names in comments).
@@ -128,25 +129,6 @@ size_t ltr_workspace_bytes(ltr_handle h /* may be NULL for LTR_WS_RANK */, int32
 /* Tokens processed per internal pass of ltr_score (request-aligned chunks keep the
  * activations of a pass resident in the 256 MiB Infinity Cache).  0 restores the default. */
 int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens);
-/* Lanes.  A mid-sized scoring call - from 2.1 M activation elements per layer (2,735 tokens at H = 768, 2,051 at H = 1024) to
- * 49,152 tokens: a scheduler step with tens to hundreds of arrivals - runs as two
- * request-aligned halves on two streams - the caller's and one the handle owns - joined before the call returns control of
- * the caller's stream: ordering on `stream` is what it is without them, the scores are those of the two halves scored on
- * their own, and ltr_workspace_bytes accounts for the second set of activations (a smaller workspace is not an error: the
- * call then runs on one lane).  ltr_lane_calls: how many calls on this handle have run on two lanes (monitoring, tests). */
-int64_t ltr_lane_calls(ltr_handle h);
-/* Whether the two lanes really run side by side is a property of the PROCESS: the HIP runtime multiplexes all streams of a
- * process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a lane stream that lands on the hardware queue of
- * the caller's stream runs its half AFTER the caller's, slower than one lane.  ltr_create therefore probes (two 150 us spin
- * kernels, one per stream, fork / join) and keeps a lane stream only if it overlaps with `stream`; candidates are tried at
- * normal, then at high priority (a queue of its own class); when none overlaps the handle runs on one lane.  A call made
- * while `stream` is being captured into a graph also runs on one lane (the split is taken from the HOST copy of cu_seqlens,
- * which a replay would freeze).
- * ltr_lane_probe repeats the measurement on any stream (synchronises it): solo_us = one spin kernel on `stream`,
- * pair_us = one on each stream between fork and join (pair_us ~ solo_us: concurrent; ~ 2 x: the streams alias);
- * returns the number of candidate streams ltr_create tried (0: the handle has no lane stream; negative LTR_E_* on error). */
-int ltr_lane_probe(ltr_handle h, void* stream, float* solo_us, float* pair_us);
-
 /* The predictor forward for a flat varlen batch: replaces one drain of the AUX
  * engine, i.e. AUXLLMEngine.obtain_aux_scores' step loop (vllm/engine/
  * aux_llm_engine.py:398-405) = ModelRunner.execute_model (vllm/worker/

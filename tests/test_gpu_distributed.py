@@ -141,7 +141,7 @@ def _worker_driver_mode(rank, world, port, q):
             ranker = MI355XRanker(sc, "opt-xxx-starv3-period2", max_length=160, group=dist.group.WORLD, driver_rank=driver,
                                   min_requests_to_shard=64, collective_timeout_s=120.0)
             served = ranker.serve()
-            q.put((rank, "worker", served, ranker.scorer.ln_fold, sc.lane_calls()))
+            q.put((rank, "worker", served, ranker.scorer.ln_fold))
             return
         n = 700
         lens = bench_lengths(n, seed=5, mu=24.0).clip(1, 150)

@@ -21,13 +21,13 @@ LTR_WT_GLOBAL_COUNT, LTR_WL_COUNT = 7, 12
 
 # every symbol include/ltr_hip.h declares (tests check the library exports them all)
 SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "ltr_workspace_bytes",
-           "ltr_set_chunk_tokens", "ltr_lane_calls", "ltr_lane_probe", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
+           "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
            "ltr_train_step", "ltr_train_read", "ltr_attention", "ltr_train_attention",
            "ltr_train_attention_workspace_bytes")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 LTR_E_INVAL, LTR_E_RANGE = -22, -34
@@ -47,7 +47,7 @@ class ModelDesc(C.Structure):
         "pos_rows", "num_labels", "pre_ln", "weight_dtype", "flags")]
 
 
-LTR_F_NO_LN_FOLD, LTR_F_NO_LANES, LTR_F_ONE_PASS, LTR_F_LANES_UNPROBED = 1, 2, 4, 8
+LTR_F_NO_LN_FOLD, LTR_F_ONE_PASS = 1, 4          # (2, 8: the lane flags of ABI 5, accepted and ignored)
 
 
 class HeadDesc(C.Structure):
@@ -109,9 +109,6 @@ def _load() -> C.CDLL:
     lib.ltr_workspace_bytes.argtypes = [vp, i32, i64, i64]
     lib.ltr_workspace_bytes.restype = sz
     lib.ltr_set_chunk_tokens.argtypes = [vp, i32]
-    lib.ltr_lane_calls.argtypes = [vp]
-    lib.ltr_lane_calls.restype = C.c_int64
-    lib.ltr_lane_probe.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ltr_score.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.ltr_forward_hidden.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.ltr_embed_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
@@ -140,7 +137,7 @@ def _load() -> C.CDLL:
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version", "ltr_train_workspace_bytes",
-                        "ltr_train_attention_workspace_bytes", "ltr_lane_calls"):
+                        "ltr_train_attention_workspace_bytes"):
             fn.restype = C.c_int
     if lib.ltr_abi_version() != ABI_VERSION:
         raise LtrError(f"{LIB_PATH} has ABI version {lib.ltr_abi_version()}, this binding needs {ABI_VERSION}: rebuild")

@@ -67,9 +67,7 @@ def build(force: bool = False) -> str:
 # element-level checker of the GEMM's LayerNorm-fold epilogues (diag/gemm_check.hip), run by the -m gpu tests
 TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip"),
          # times the four dense layers of a decoder layer at M rows through launch_gemm (A/B of tile / split-K / XCD-map choices)
-         "gemm_bench": os.path.join("diag", "gemm_bench.hip"),
-         # the GEMMs of two half batches on two streams against the whole batch on one (the "lanes" of run_forward)
-         "lanes_probe": os.path.join("diag", "lanes_probe.hip")}
+         "gemm_bench": os.path.join("diag", "gemm_bench.hip")}
 # reproducers of the round-5 concurrency fault (profiles/r06_rln_fault.txt); they compile ltr_gemm.hip into themselves and use
 # rocBLAS as the co-running library GEMM: name -> (source, extra flags)
 ROCBLAS = os.path.exists("/opt/rocm/lib/librocblas.so") and os.path.exists("/opt/rocm/include/rocblas/rocblas.h")

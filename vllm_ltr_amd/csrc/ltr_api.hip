@@ -10,7 +10,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -68,23 +67,8 @@ struct ltr_model {
   const void* proj_out_w = nullptr;
   const void* head_w = nullptr;
   int head_lpad = 0;
-  // Lanes (run_forward): a second stream + fork / join events, so that the two halves of a mid-sized batch run concurrently.
-  // lane_mu serialises the ENQUEUE section of calls that use them (calls that find it taken run on one lane).
-  hipStream_t lane_stream = nullptr;
-  hipEvent_t lane_fork = nullptr, lane_join = nullptr;
-  std::mutex lane_mu;
-  std::atomic<int64_t> lane_calls{0};
-  bool lane_probe_on = true;       // false: LTR_F_LANES_UNPROBED / LTR_LANE_PROBE=0 (the first candidate is used as it is)
-  int lane_tries = 0;              // candidate streams ltr_create probed before it kept one (ltr_lane_probe reports it)
-  // caller streams the lane stream has been probed against (guarded by lane_mu): (stream, runs beside it).  ltr_create
-  // probes against ITS stream; a call on another stream (a prescore side stream, a worker thread's stream) probes once,
-  // on its first lane-sized call (one host synchronisation of that stream, ~0.1 ms).
-  std::vector<std::pair<hipStream_t, bool>> lane_seen;
   bool one_pass = false;           // LTR_F_ONE_PASS: the GEMMs / attention multiply the hi plane only
   ~ltr_model() {
-    if (lane_stream) (void)hipStreamDestroy(lane_stream);
-    if (lane_fork) (void)hipEventDestroy(lane_fork);
-    if (lane_join) (void)hipEventDestroy(lane_join);
     if (packed) (void)hipFree(packed);
     if (fold) (void)hipFree(fold);
     if (err_flag) (void)hipFree(err_flag);
@@ -136,22 +120,6 @@ inline int64_t stats_comb_min_rows() {
 
 // passes of at most this many rows get the small-batch split-K scratch (launch_gemm decides per launch)
 constexpr int64_t SPLITK_MAX_ROWS = 4800;
-
-// Lanes (run_forward): mid-sized batches run as two halves on two streams.  LTR_LANES: 0 never, 1 (default) in the range below,
-// 2 whenever the batch has two requests (lab); LTR_LANES_MIN / LTR_LANES_MAX move the range (tokens).  Measured
-// (profiles/r04_lanes_lab.txt, profiles/r05_lanes_threshold.txt): -4 ... -14 % per call from ~2,750 tokens (OPT-125m) / ~2,100
-// (OPT-350m) to 44k tokens, +-1 % from 64k up; BELOW that the halves pick kernels sized for ~1k rows and two lanes lose 2-17 % in
-// most of the range (round 4's lower end of 1,200 tokens came from a coarse grid that happened to hit the winning points):
-// the lower end is 2.1 M activation elements per layer, i.e. 2,735 tokens at H = 768 and 2,051 at H = 1024.
-inline int lanes_mode() { static const int v = [] { const char* e = getenv("LTR_LANES"); return e ? atoi(e) : 1; }(); return v; }
-inline bool lanes_for_tokens(int64_t T, int H) {
-  // (read per call - a getenv costs nothing next to a scoring call - so that a test can move the range)
-  const char* e_lo = getenv("LTR_LANES_MIN");
-  const char* e_hi = getenv("LTR_LANES_MAX");
-  const int64_t lo_env = e_lo ? atoll(e_lo) : -1, hi = e_hi ? atoll(e_hi) : 49152;
-  const int64_t lo = lo_env >= 0 ? lo_env : (2100000 + H - 1) / (H > 0 ? H : 1);
-  return lanes_mode() >= 2 || (lanes_mode() == 1 && T >= lo && T <= hi);
-}
 
 // workspace carve-up for one chunk of at most Tc tokens / Nc requests
 struct Workspace {
@@ -256,7 +224,8 @@ struct ProfScope {
 };
 
 // One request-aligned chunk: requests [r0, r1), tokens [t0, t1) of the global batch - as a stepper (begin, then one call per
-// decoder layer), so that run_forward can issue the layers of two independent chunks ALTERNATELY onto two streams ("lanes").
+// decoder layer).  (Rounds 4-5 issued the layers of two half batches alternately onto two streams, "lanes": measured again and
+// removed in round 6, profiles/r06_lanes_after.txt.)
 struct ChunkRun {
   const ltr_model* m;
   const int64_t* ids;
@@ -496,64 +465,6 @@ int ChunkRun::layer(const int L) {
   return LTR_OK;
 }
 
-// ---- lane-stream probe.  Two streams of a process run side by side only if the runtime mapped them to different hardware
-// queues (GPU_MAX_HW_QUEUES, 4 by default, shared by every stream of the process); on the same queue the lane's half runs
-// after the caller's - slower than one lane (GPUTEST_r04: k = 64 in 3.93 ms in a process with dozens of handles, 2.91 in
-// bench.py; alternating submissions of two streams into ONE hardware queue also pay a dependency per launch).  A spin of
-// SPIN_TICKS of the 100 MHz wall clock on each stream between fork and join tells the two cases apart; it must be long
-// against the fork / join latency itself (~25 us: a 20-us spin read "serial" for streams that do overlap, gpurun r05a).
-constexpr long long SPIN_TICKS = 15000;   // 150 us
-__global__ void lane_spin_kernel(long long ticks) {
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-// solo_us: one spin on s; pair_us: one on s and one on lane between fork and join (events on s around both)
-int lane_probe(hipStream_t s, hipStream_t lane, hipEvent_t fork, hipEvent_t join, float* solo_us, float* pair_us) {
-  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipGetLastError();
-    set_error("lane probe: cannot create events");
-    return LTR_E_HIP;
-  }
-  int rc = LTR_OK;
-  auto run = [&]() -> int {
-    lane_spin_kernel<<<1, 64, 0, s>>>(200);                      // warm both streams (code object load, queue creation)
-    LTR_HIP_CHECK(hipEventRecord(fork, s));
-    LTR_HIP_CHECK(hipStreamWaitEvent(lane, fork, 0));
-    lane_spin_kernel<<<1, 64, 0, lane>>>(200);
-    LTR_HIP_CHECK(hipEventRecord(join, lane));
-    LTR_HIP_CHECK(hipStreamWaitEvent(s, join, 0));
-    LTR_HIP_CHECK(hipEventRecord(e0, s));
-    lane_spin_kernel<<<1, 64, 0, s>>>(SPIN_TICKS);
-    LTR_HIP_CHECK(hipEventRecord(e1, s));
-    LTR_HIP_CHECK(hipEventRecord(fork, s));
-    LTR_HIP_CHECK(hipStreamWaitEvent(lane, fork, 0));
-    lane_spin_kernel<<<1, 64, 0, s>>>(SPIN_TICKS);
-    lane_spin_kernel<<<1, 64, 0, lane>>>(SPIN_TICKS);
-    LTR_HIP_CHECK(hipEventRecord(join, lane));
-    LTR_HIP_CHECK(hipStreamWaitEvent(s, join, 0));
-    LTR_HIP_CHECK(hipEventRecord(e2, s));
-    LTR_HIP_CHECK(hipEventSynchronize(e2));
-    float a = 0.f, b = 0.f;
-    LTR_HIP_CHECK(hipEventElapsedTime(&a, e0, e1));
-    LTR_HIP_CHECK(hipEventElapsedTime(&b, e1, e2));
-    *solo_us = a * 1e3f; *pair_us = b * 1e3f;
-    return LTR_OK;
-  };
-  rc = run();
-  if (rc) {     // a failure between fork and join: the caller's stream must still not run ahead of what the lane was given
-    (void)hipEventRecord(join, lane);
-    (void)hipStreamWaitEvent(s, join, 0);
-    (void)hipGetLastError();
-  }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-  return rc;
-}
-inline bool lanes_overlap(float solo_us, float pair_us) { return pair_us < 1.6f * solo_us; }
-
 int check_desc(const ltr_model_desc& d) {
   if (d.hidden_size <= 0 || d.num_heads <= 0 || d.hidden_size != d.num_heads * 64) {
     set_error("ltr_create: head size must be 64 (H=%d, heads=%d)", d.hidden_size, d.num_heads);
@@ -654,37 +565,6 @@ int ltr_create(const ltr_model_desc* desc, const void* const* weights, int32_t n
   }
   { const char* e = getenv("LTR_DEBUG_ATTN_VALU"); m->dbg_attn_valu = e && e[0] == '1'; }
   m->one_pass = (desc->flags & LTR_F_ONE_PASS) != 0;
-  if (lanes_mode() > 0 && desc->weight_dtype == LTR_W_F16 && !(desc->flags & LTR_F_NO_LANES)) {
-    // second lane for mid-sized batches (run_forward); optional.  Keep a candidate only if it runs BESIDE `stream` (lane_probe):
-    // up to three streams at normal priority, then one at the highest priority (its own hardware-queue class).  Rejected
-    // candidates stay alive until the choice is made, so that the next one is mapped to another queue.  LTR_LANE_PROBE=0
-    // keeps the first candidate unprobed (the round-4 behaviour; lab).
-    static const bool probe_env = [] { const char* e = getenv("LTR_LANE_PROBE"); return !(e && e[0] == '0'); }();
-    const bool probe_on = probe_env && !(desc->flags & LTR_F_LANES_UNPROBED);
-    m->lane_probe_on = probe_on;
-    if (hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&m->lane_join, hipEventDisableTiming) == hipSuccess) {
-      int lo_pri = 0, hi_pri = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
-      std::vector<hipStream_t> rejected;
-      for (int attempt = 0; attempt < 4 && !m->lane_stream; ++attempt) {
-        hipStream_t cand = nullptr;
-        const hipError_t e = attempt < 3 ? hipStreamCreateWithFlags(&cand, hipStreamNonBlocking)
-                                         : hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, hi_pri);
-        if (e != hipSuccess) { (void)hipGetLastError(); break; }
-        m->lane_tries = attempt + 1;
-        float solo = 0.f, pair = 0.f;
-        if (!probe_on || (lane_probe(cs, cand, m->lane_fork, m->lane_join, &solo, &pair) == LTR_OK && lanes_overlap(solo, pair))) {
-          m->lane_stream = cand;
-          if (probe_on) m->lane_seen.emplace_back(cs, true);
-        }
-        else
-          rejected.push_back(cand);
-      }
-      for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-    }
-    (void)hipGetLastError();
-  }
   m->wg = m->w;
   if (desc->weight_dtype == LTR_W_F16) {
     // one-time re-layout of the dense-layer weights into the GEMM kernel's slab-major image
@@ -808,18 +688,6 @@ int ltr_status(ltr_handle h, void* stream) {
   return LTR_OK;
 }
 
-int64_t ltr_lane_calls(ltr_handle h) { return h ? h->lane_calls.load(std::memory_order_relaxed) : 0; }
-
-int ltr_lane_probe(ltr_handle h, void* stream, float* solo_us, float* pair_us) {
-  if (!h || !solo_us || !pair_us) { set_error("ltr_lane_probe: NULL argument"); return LTR_E_INVAL; }
-  *solo_us = *pair_us = 0.f;
-  if (!h->lane_stream) return 0;
-  DeviceGuard guard(h->device);
-  std::lock_guard<std::mutex> lk(h->lane_mu);          // the fork / join events belong to calls that hold this lock
-  const int rc = lane_probe((hipStream_t)stream, h->lane_stream, h->lane_fork, h->lane_join, solo_us, pair_us);
-  return rc ? rc : h->lane_tries;
-}
-
 int ltr_set_chunk_tokens(ltr_handle h, int32_t chunk_tokens) {
   if (!h || chunk_tokens < 0) { set_error("ltr_set_chunk_tokens: bad argument"); return LTR_E_INVAL; }
   h->chunk_tokens = chunk_tokens == 0 ? DEFAULT_CHUNK_TOKENS : chunk_tokens;
@@ -832,15 +700,6 @@ size_t ltr_workspace_bytes(ltr_handle h, int32_t kind, int64_t N, int64_t T) {
     int64_t Tc = T < chunk_cap(h) ? T : chunk_cap(h);
     int64_t Nc = N < Tc ? N : Tc;
     const size_t one = carve(h->d, Tc > 0 ? Tc : 1, Nc > 0 ? Nc : 1, nullptr, h->ln_fold, head_mode(h)).bytes;
-    if (h->lane_stream && T <= chunk_cap(h) && N >= 2 && lanes_for_tokens(T, h->d.hidden_size)) {
-      // two lanes: the cut is the request boundary closest to the middle, so a half holds at most T / 2 tokens plus half
-      // a request of maximal length - and at most as many requests as tokens
-      int64_t Th = T / 2 + (h->d.pos_rows - 2 + 1) / 2 + 1;
-      if (Th > T) Th = T;
-      const int64_t Nh = N - 1 < Th ? N - 1 : Th;
-      const size_t two = 2 * align_up(carve(h->d, Th, Nh > 0 ? Nh : 1, nullptr, h->ln_fold, head_mode(h)).bytes);
-      return two > one ? two : one;
-    }
     return one;
   }
   return 0;
@@ -961,69 +820,6 @@ static int run_forward(ltr_handle h, const int64_t* token_ids, const int32_t* cu
     const int t0 = cu[r0], t1 = cu[r1];
     const bool prune = !hidden_out && d.num_layers > 0;
     auto sum_sq = [&](int a_, int b_) { double v = 0.0; for (int r = a_; r < b_; ++r) { const double L = cu[r + 1] - cu[r]; v += L * L; } return v; };
-    // ---- lanes: a mid-sized batch (tens to hundreds of arrivals of a scheduler step) as TWO request-aligned halves on two
-    // streams, their layers issued alternately.  In that regime a launch has too few tiles for the chip, or a last round
-    // that is mostly empty, and its prologue / epilogue are exposed (profiles/r04_small_gemm_lab.txt); the halves are
-    // independent (a request never reads another request's state), so one half's under-filled launches run beside the
-    // other's.  Each half is exactly the call one would make for it alone (same kernels, same results).
-    int r_mid = -1;
-    bool capturing = false;            // a captured call must not depend on the host copy of cu_seqlens beyond (N, T): one lane
-    if (h->lane_stream) {
-      hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(s, &cst) != hipSuccess) (void)hipGetLastError();
-      capturing = cst != hipStreamCaptureStatusNone;
-    }
-    if (!hidden_out && r0 == 0 && r1 == N && N >= 2 && h->lane_stream && !capturing && lanes_for_tokens(t1 - t0, d.hidden_size)) {
-      const int64_t half = (t1 - t0) / 2;
-      r_mid = 1;
-      while (r_mid + 1 < N && cu[r_mid + 1] - t0 <= half) ++r_mid;              // first cut at or past the middle ...
-      if (r_mid + 1 < N && (cu[r_mid + 1] - t0) - half < half - (cu[r_mid] - t0)) ++r_mid;   // ... or the one before, whichever is closer
-    }
-    std::unique_lock<std::mutex> lane_lock(h->lane_mu, std::defer_lock);
-    if (r_mid > 0 && !lane_lock.try_lock()) r_mid = -1;
-    Workspace wa{}, wb{};
-    if (r_mid > 0) {                   // the two halves' scratch must fit what the caller gave (checked BEFORE any probing)
-      const int tm_ = cu[r_mid];
-      wa = carve(d, tm_ - t0, r_mid - r0, workspace, h->ln_fold, head_mode(h));
-      wb = carve(d, t1 - tm_, r1 - r_mid, (char*)workspace + align_up(wa.bytes), h->ln_fold, head_mode(h));
-      if (align_up(wa.bytes) + wb.bytes > ws_bytes) { r_mid = -1; lane_lock.unlock(); }
-    }
-    if (r_mid > 0) {                   // does the lane stream run beside THIS caller stream?  (probed once per stream; ltr_lane_probe
-                                       // pre-probes a stream outside the scoring path.  The verdict is keyed by the stream HANDLE: a
-                                       // destroyed stream whose handle value is reused inherits it - worst case one lane where two would do)
-      bool known = !h->lane_probe_on, ok = true;
-      for (auto& e : h->lane_seen) if (e.first == s) { known = true; ok = e.second; }
-      if (!known) {
-        float solo = 0.f, pair = 0.f;
-        ok = lane_probe(s, h->lane_stream, h->lane_fork, h->lane_join, &solo, &pair) == LTR_OK && lanes_overlap(solo, pair);
-        if (h->lane_seen.size() >= 16) h->lane_seen.erase(h->lane_seen.begin());
-        h->lane_seen.emplace_back(s, ok);
-      }
-      if (!ok) { r_mid = -1; lane_lock.unlock(); }
-    }
-    if (r_mid > 0) {
-      const int tm_ = cu[r_mid];
-      {
-        hipStream_t s2 = h->lane_stream;
-        LTR_HIP_CHECK(hipEventRecord(h->lane_fork, s));
-        LTR_HIP_CHECK(hipStreamWaitEvent(s2, h->lane_fork, 0));
-        ChunkRun ca(h, token_ids, cu_seqlens, N, r0, r_mid, t0, tm_, n_layers, wa, sum_sq(r0, r_mid), prune, s);
-        ChunkRun cb(h, token_ids, cu_seqlens, N, r_mid, r1, tm_, t1, n_layers, wb, sum_sq(r_mid, r1), prune, s2);
-        rc = ca.begin();
-        if (!rc) rc = cb.begin();
-        for (int L = 0; !rc && L < ca.nl; ++L) { rc = ca.layer(L); if (!rc) rc = cb.layer(L); }
-        if (!rc) rc = finish_chunk(ca);
-        if (!rc) rc = finish_chunk(cb);
-        // join even after an error: the caller's stream must not run ahead of work already queued on the lane
-        (void)hipEventRecord(h->lane_join, s2);
-        (void)hipStreamWaitEvent(s, h->lane_join, 0);
-        if (rc) return rc;
-        h->lane_calls.fetch_add(1, std::memory_order_relaxed);
-        r0 = r1;
-        continue;
-      }
-    }
-    if (lane_lock.owns_lock()) lane_lock.unlock();
     Workspace ws = carve(d, t1 - t0, r1 - r0, workspace, h->ln_fold, head_mode(h));
     if (ws.bytes > ws_bytes) { set_error("ltr_score: workspace too small (%zu < %zu)", ws_bytes, ws.bytes); return LTR_E_NOMEM; }
     if (hidden_out && (r0 != 0 || r1 != N)) { set_error("ltr_forward_hidden: batch does not fit one chunk"); return LTR_E_NOMEM; }

@@ -608,7 +608,6 @@ class MI355XRanker:
                               last=pct(self._rank_ms)),
                     live_slots=self._live_slots, queue_length=self._n_members,
                     sharded=self._sharded is not None, range_fallbacks=st["range_fallbacks"],
-                    two_lane_calls=self.scorer.lane_calls() if hasattr(self.scorer, "lane_calls") else 0,
                     prescore=dict(enabled=self.prescore, launches=st["prescore_launches"],
                                   graph_replays=st["prescore_graph_replays"], requests=st["prescored_requests"],
                                   orphans=st["prescore_orphans"], inflight=len(self._pre_inflight),

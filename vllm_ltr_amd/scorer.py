@@ -27,12 +27,10 @@ class HipOPTScorer:
     scores, outside the 1e-4 contract of the default; `LTR_F_ONE_PASS`).
     ln_fold=False: separate LayerNorm launches instead of the GEMM-epilogue fold
     (`LTR_F_NO_LN_FOLD`: the handle a caller falls back to on LTR_E_RANGE).
-    lanes=False: never split a call over two streams (`LTR_F_NO_LANES`); lanes="unprobed": keep the lane stream
-    without the overlap probe (`LTR_F_LANES_UNPROBED`: tests of the two-lane arithmetic).
     """
 
     def __init__(self, spec: OPTSpec, ckpt: Dict[str, np.ndarray], device: str = "cuda:0",
-                 weight_dtype: str = "f16", chunk_tokens: int = 0, ln_fold: bool = True, lanes: bool = True):
+                 weight_dtype: str = "f16", chunk_tokens: int = 0, ln_fold: bool = True):
         if not torch.cuda.is_available():
             raise _lib.LtrError("HipOPTScorer needs a ROCm GPU (no CPU fallback on the product path)")
         self.lib = _lib.load()
@@ -44,7 +42,7 @@ class HipOPTScorer:
             raise _lib.LtrError(f"weight_dtype {weight_dtype!r}: expected 'f16', 'f32' or 'f16-1pass'")
         self.weight_dtype = weight_dtype
         self.one_pass = weight_dtype == "f16-1pass"
-        self.ln_fold, self.lanes = bool(ln_fold), lanes if lanes == "unprobed" else bool(lanes)
+        self.ln_fold = bool(ln_fold)
         self._ckpt_ref = ckpt              # (a twin handle without the fold is built from the same arrays: unfolded_twin)
         weight_dtype = "f16" if self.one_pass else weight_dtype
         wt = torch.float16 if weight_dtype == "f16" else torch.float32
@@ -91,7 +89,7 @@ class HipOPTScorer:
                               spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
                               1 if spec.do_layer_norm_before else 0,
                               _lib.LTR_W_F16 if weight_dtype == "f16" else _lib.LTR_W_F32,
-                              (0 if ln_fold else _lib.LTR_F_NO_LN_FOLD) | self._lane_flags() |
+                              (0 if ln_fold else _lib.LTR_F_NO_LN_FOLD) |
                               (_lib.LTR_F_ONE_PASS if self.one_pass else 0))
         self._h = C.c_void_p()
         # the library packs the dense-layer weights on THIS stream (ordered after the uploads above, which
@@ -120,16 +118,13 @@ class HipOPTScorer:
         self.chunk_tokens = int(n)
         self._ws = None
 
-    def _lane_flags(self) -> int:
-        return _lib.LTR_F_LANES_UNPROBED if self.lanes == "unprobed" else (0 if self.lanes else _lib.LTR_F_NO_LANES)
-
     def unfolded_twin(self) -> "HipOPTScorer":
         """A scorer of the same checkpoint whose GEMMs are fed by separate LayerNorm launches (`LTR_F_NO_LN_FOLD`):
         what `MI355XRanker` re-scores a batch on when this handle reports LTR_E_RANGE.  Shares the weight tensors
         (the library keeps pointers; only its packed GEMM images are per handle)."""
         twin = HipOPTScorer.__new__(HipOPTScorer)
         twin.lib, twin.spec, twin.device = self.lib, self.spec, self.device
-        twin.weight_dtype, twin.one_pass, twin.ln_fold, twin.lanes = self.weight_dtype, self.one_pass, False, self.lanes
+        twin.weight_dtype, twin.one_pass, twin.ln_fold = self.weight_dtype, self.one_pass, False
         twin._ckpt_ref = self._ckpt_ref
         twin._tensors = self._tensors
         g = self._tensors
@@ -140,7 +135,7 @@ class HipOPTScorer:
                               spec.max_position_embeddings + spec.POS_OFFSET, spec.num_labels,
                               1 if spec.do_layer_norm_before else 0,
                               _lib.LTR_W_F32 if self.weight_dtype == "f32" else _lib.LTR_W_F16,
-                              _lib.LTR_F_NO_LN_FOLD | self._lane_flags() | (_lib.LTR_F_ONE_PASS if self.one_pass else 0))
+                              _lib.LTR_F_NO_LN_FOLD | (_lib.LTR_F_ONE_PASS if self.one_pass else 0))
         twin._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ltr_create(C.byref(desc), ptrs, len(g), self._stream(), C.byref(twin._h)), "ltr_create")
@@ -157,20 +152,6 @@ class HipOPTScorer:
         self._ws = None
         for k in keys:
             self._ws_by_key.pop(k, None)
-
-    def lane_probe(self):
-        """(candidates ltr_create tried, us of one 20-us spin kernel on the current stream, us of one on each of the two
-        lanes between fork and join): pair ~ solo means the lanes run side by side (include/ltr_hip.h "Lanes")."""
-        solo, pair = C.c_float(), C.c_float()
-        with torch.cuda.device(self.device):
-            rc = self.lib.ltr_lane_probe(self._h, self._stream(), C.byref(solo), C.byref(pair))
-        if rc < 0:
-            _lib.check(rc, "ltr_lane_probe")
-        return int(rc), float(solo.value), float(pair.value)
-
-    def lane_calls(self) -> int:
-        """Scoring calls on this handle that ran as two halves on two streams (include/ltr_hip.h "Lanes")."""
-        return int(self.lib.ltr_lane_calls(self._h))
 
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.ltr_profile_enable(self._h, 1 if on else 0), "ltr_profile_enable")
