@@ -90,3 +90,35 @@ class InputStager:
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
         return self._sc_h.numpy()[:n]
+
+
+class PinnedI32:
+    """Growable pinned int32 staging buffer + device twin (members / ran slots / permutation)."""
+
+    def __init__(self, device, cap: int = 1 << 13):
+        self.device = device
+        self._evt = None
+        self._grow(cap)
+
+    def _grow(self, cap: int):
+        self.cap = cap
+        self.host = torch.empty(cap, dtype=torch.int32).pin_memory()
+        self.np = self.host.numpy()
+        self.dev = torch.empty(cap, dtype=torch.int32, device=self.device)
+        self._evt = None
+
+    def ensure(self, n: int):
+        """Call before writing ``self.np``: grows the buffers and waits until the previous asynchronous upload has
+        read the pinned buffer (normally long done)."""
+        if self._evt is not None:
+            self._evt.synchronize()
+            self._evt = None
+        if n > self.cap:
+            self._grow(max(n, 2 * self.cap))
+
+    def upload(self, n: int) -> torch.Tensor:
+        d = self.dev[:n]
+        d.copy_(self.host[:n], non_blocking=True)
+        self._evt = torch.cuda.Event()
+        self._evt.record(torch.cuda.current_stream(self.device))
+        return d
