@@ -1,8 +1,9 @@
 """ISA lint of the built gfx950 code objects: no packed-f32 instruction may select the HIGH register of src1 for its lo lane.
 
 Why (profiles/r06_rln_fault.txt): on MI355X, `v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32` with `op_sel[1] = 1, op_sel[0] = 0`
-(`op_sel:[0,1]`, `op_sel:[0,1,x]`) return a wrong lo half - the src1 term reads as zero - in lanes 48-63 whenever waves of a
-library fp16 GEMM kernel share the CU; every other operand-select placement (`[1,0]`, `[1,1]`, any `op_sel_hi`, src2) computes
+(`op_sel:[0,1]`, `op_sel:[0,1,x]`) return a wrong lo half - the src1 term reads as zero - in lanes 48-63 whenever a wave on the
+same SIMD issues gfx950's K-doubled MFMA forms (v_mfma_f32_32x32x16_* / 16x16x32_*: a library fp16 / bf16 GEMM, or this
+library's own GEMM and attention kernels on another stream); every other operand-select placement (`[1,0]`, `[1,1]`, any `op_sel_hi`, src2) computes
 correctly in the same test (diag/pk_opsel_probe.hip: 4 of 4 runs, ~130,000 wrong values per 16 M; 0 for the other forms).
 hipcc emits the form when the y component of a float2 that lives in ONE 64-bit register (a 64-bit load, a phi of float2)
 feeds vectorised f32 math; round 5 met it as "scores off by 1e-2 whenever another stream has a kernel in flight" in one
