@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LTR_ABI_VERSION 6
+#define LTR_ABI_VERSION 7
 
 enum {
   LTR_OK = 0,
@@ -346,9 +346,24 @@ int ltr_listmle(const float* y_pred, const float* y_true, const int32_t* shuffle
                 float eps, float pad_value, float* loss_out, float* row_loss_out, float* grad_out,
                 void* stream);
 
+/* The reference's other ranking loss, `--loss neuralNDCG` (train/trainer.py:127-128 -> train/allrank/models/losses/
+ * neuralNDCG.py:27-87, deterministic variant = the defaults the trainer calls it with; NeuralSort and Sinkhorn scaling of
+ * losses/loss_utils.py:24-83, ideal DCG of models/metrics.py:89-135) and its gradient w.r.t. the predictions (what autograd
+ * yields through the unrolled Sinkhorn rounds).  y_pred, y_true f32 [B, S]; items with y_true == pad_value are masked;
+ * temperature = NeuralSort's tau (1); k = rank the metric is cut at (<= 0 or > S: the slate length, the reference's None).
+ * loss_out f32 [1] = -mean NDCG over the slates whose ideal DCG is not 0 (none: 0 and a zero gradient); row_ndcg_out f32 [B];
+ * grad_out f32 [B, S] or NULL.  2 <= S <= 1024 (S = 1: LTR_E_INVAL - the reference raises IndexError, loss_utils.py:70).
+ * The Sinkhorn loop stops, as the reference's, after the first round in which every slate OF THE BATCH is within 1e-6.
+ * Gains are 2^label - 1 in f32: a label of 128 or more makes the loss NaN, here as in the reference.
+ * workspace: ltr_neuralndcg_workspace_bytes(B, S) bytes (0 for an unsupported shape), device. */
+size_t ltr_neuralndcg_workspace_bytes(int32_t B, int32_t S);
+int ltr_neuralndcg(const float* y_pred, const float* y_true, int32_t B, int32_t S, float temperature, int32_t k,
+                   float pad_value, float* loss_out, float* row_ndcg_out, float* grad_out, void* workspace,
+                   size_t ws_bytes, void* stream);
+
 /* The other half of SURVEY.md 8f-4: ONE optimisation step of the predictor's fine-tuning loop,
  * train/trainer.py:122-165 - forward of the OPTForSequenceClassification predictor on a slate of prompts
- * (prefill_predictor.py:76-79), loss_func(outputs.view(1, -1), labels) with listMLE / MSELoss or CrossEntropyLoss over
+ * (prefill_predictor.py:76-79), loss_func(outputs.view(1, -1), labels) with listMLE / neuralNDCG / MSELoss or CrossEntropyLoss over
  * num_labels classes (:125-157), loss.backward(), torch.optim.Adam(lr, weight_decay).step() (:122,161-165: L2 decay added
  * to the gradient, bias-corrected moments), optimizer.zero_grad().  Parameters, activations, gradients and moments are f32
  * (fp32 master weights, :99-101); the dense layers multiply on the fp16 matrix cores with both operands split into two
@@ -357,7 +372,7 @@ int ltr_listmle(const float* y_pred, const float* y_true, const int32_t* shuffle
  * ltr_train_create COPIES the f32 weights (same pointer order as ltr_create, every tensor f32) into library-owned
  * parameter / gradient / moment buffers; ltr_train_read copies the current value of a tensor out, for evaluation and
  * for writing the fine-tuned checkpoint (trainer.py:213-216 saves it .half()). */
-enum { LTR_LOSS_LISTMLE = 0, LTR_LOSS_MSE = 1, LTR_LOSS_CROSSENTROPY = 2 };
+enum { LTR_LOSS_LISTMLE = 0, LTR_LOSS_MSE = 1, LTR_LOSS_CROSSENTROPY = 2, LTR_LOSS_NEURALNDCG = 3 };
 enum { LTR_TRAIN_PREC_DEFAULT = 0, LTR_TRAIN_PREC_SPLIT = 1, LTR_TRAIN_PREC_F32 = 2 };
 typedef struct ltr_train_config {
   float lr;            /* trainer.py --lr (2e-5) */
@@ -380,7 +395,7 @@ int ltr_train_create(const ltr_model_desc* desc, const void* const* weights, int
 int ltr_train_destroy(ltr_train_handle h);
 size_t ltr_train_workspace_bytes(ltr_train_handle h, int64_t N, int64_t T);
 /* One step on a slate of N prompts (flat ids / cu_seqlens as ltr_score; the whole slate is one pass).
- *   labels   f32 [N]: listMLE / mse targets, or class indices for crossentropy
+ *   labels   f32 [N]: listMLE / neuralNDCG / mse targets, or class indices for crossentropy (neuralNDCG: 2 <= N <= 1024)
  *   shuffle  int32 [N]: the random permutation of listMLE.py:33 (listMLE only)
  *   apply_update 1: the full step; 0: gradients only, no Adam step; -1: evaluation forward (predictor.model.eval(),
  *            trainer.py:171-190: no dropout, no loss, no backward - labels / shuffle / loss_out may be NULL, logits_out is

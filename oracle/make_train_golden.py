@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/train_steps_*.npz: a few optimisation steps of the reference's fine-tuning recipe
 (train/trainer.py:122-165) computed by the pieces the reference itself uses - HF ``OPTForSequenceClassification`` in
-fp32 (dropout 0 so that the run is reproducible), the reference's own listMLE (loaded by path from
+fp32 (dropout 0 so that the run is reproducible), the reference's own listMLE / neuralNDCG (loaded by path from
 /root/reference/train/allrank, its ``torch.randperm`` replaced by a recorded permutation), ``torch.optim.Adam``.
 Runs only in the build container:
 
@@ -60,6 +60,9 @@ def batch(spec, lens, seed):
 
 def run_case(name, spec, seed, loss_name, steps, lens_list, lr, wd):
     listMLE = load_reference_listmle()
+    if loss_name == "neuralNDCG":
+        from oracle.make_neuralndcg_golden import load_reference_neuralndcg
+        neuralNDCG = load_reference_neuralndcg()
     ckpt = seeded_checkpoint(spec, seed)
     m = hf_model(spec, ckpt)
     opt = torch.optim.Adam(m.parameters(), lr=lr, weight_decay=wd)                  # trainer.py:122
@@ -87,6 +90,10 @@ def run_case(name, spec, seed, loss_name, steps, lens_list, lr, wd):
                 loss = listMLE(logits.view(1, -1), torch.from_numpy(labels).view(1, -1))     # trainer.py:157
             finally:
                 torch.randperm = real
+        elif loss_name == "neuralNDCG":
+            labels = rs.randint(0, 12, n).astype(np.float32)                        # bucketed lengths (trainer.py:50-52), with ties
+            perm = np.arange(n)
+            loss = neuralNDCG(logits.view(1, -1), torch.from_numpy(labels).view(1, -1))      # trainer.py:127-128,157
         elif loss_name == "crossentropy":
             labels = rs.randint(0, spec.num_labels, n).astype(np.int64)
             perm = np.arange(n)
@@ -127,3 +134,4 @@ if __name__ == "__main__":
     run_case("post_ln_listmle", OPTSpec.tiny_post_ln(), 42, "listMLE", 3, a, 1e-3, 0.01)
     run_case("pre_ln_class5_ce", OPTSpec.tiny_pre_ln(5), 43, "crossentropy", 2, a, 1e-3, 0.0)
     run_case("post_ln_mse", OPTSpec.tiny_post_ln(), 44, "mse", 2, a, 5e-4, 0.01)
+    run_case("pre_ln_neuralndcg", OPTSpec.tiny_pre_ln(), 45, "neuralNDCG", 3, a, 1e-3, 0.01)

@@ -28,6 +28,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from oracle.neuralndcg import neuralndcg_torch
 from oracle.opt_scorer import OracleOPTScorer
 
 DEFAULT_EPS = 1e-10      # allrank/models/losses/__init__.py:17
@@ -91,6 +92,8 @@ class OracleTrainer:
         y = torch.as_tensor(np.asarray(labels))
         if self.loss == "listMLE":                    # trainer.py:157: the batch is one slate
             return listmle_torch(logits.view(1, -1), y.to(self.dtype).view(1, -1), torch.as_tensor(np.asarray(shuffle), dtype=torch.long))
+        if self.loss == "neuralNDCG":                 # trainer.py:127-128,157: every keyword of neuralNDCG at its default
+            return neuralndcg_torch(logits.view(1, -1), y.to(self.dtype).view(1, -1))
         if self.loss == "mse":                        # trainer.py:130,157
             return F.mse_loss(logits.view(1, -1), y.to(self.dtype).view(1, -1))
         if self.loss == "crossentropy":               # trainer.py:132,152-155

@@ -21,7 +21,7 @@ def pytest_configure(config):
 # latency bound sat in front of test_listmle / test_ltr_head / test_train_step.
 _FILE_ORDER = ["test_oracle_golden.py", "test_host_cpu.py", "test_isa_lint.py", "test_gpu_rank.py", "test_gpu_attention.py",
                "test_gpu_gemm_epilogue.py", "test_gpu_isa_hazard.py", "test_gpu_scorer.py", "test_gpu_config1.py", "test_gpu_outlier.py",
-               "test_ltr_head.py", "test_listmle.py", "test_train_step.py", "test_gpu_small_batches.py",
+               "test_ltr_head.py", "test_listmle.py", "test_neuralndcg.py", "test_train_step.py", "test_gpu_small_batches.py",
                "test_gpu_full_configs.py", "test_distributed_cpu.py", "test_gpu_distributed.py"]
 
 

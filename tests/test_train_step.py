@@ -14,7 +14,7 @@ from oracle.train_step import OracleTrainer, listmle_torch
 from util import GOLDEN, spec_from_npz
 from vllm_ltr_amd.opt_spec import seeded_checkpoint
 
-CASES = ["pre_ln_listmle", "post_ln_listmle", "pre_ln_class5_ce", "post_ln_mse"]
+CASES = ["pre_ln_listmle", "post_ln_listmle", "pre_ln_class5_ce", "post_ln_mse", "pre_ln_neuralndcg"]
 
 
 def sample_index(size: int, k: int = 2048) -> np.ndarray:
@@ -40,6 +40,13 @@ def _final_close(got, want, name, lr, wd, n_steps):
         assert (d <= tol).mean() >= 0.995 and d.max() <= 1.01 * lr * n_steps, f"{name}: {(d > tol).sum()} of {d.size} beyond {tol:.1e}, max {d.max():.3e}"
 
 
+def _after_update_tol(loss_name: str, base: float) -> float:
+    """Logits AFTER an update.  NeuralNDCG's gradients are ~50x smaller than ListMLE's (the loss lives in [-1, 0]), so more
+    entries of the model have |g| near f32 rounding noise, where Adam's m / (sqrt(v) + eps) turns noise into +-lr steps:
+    two correct implementations drift apart by a few 1e-5 per step at lr 1e-3."""
+    return 2e-4 if loss_name == "neuralNDCG" else base
+
+
 def _load(case):
     z = np.load(os.path.join(GOLDEN, f"train_steps_{case}.npz"))
     return z, spec_from_npz(z), str(z["loss_name"]), float(z["lr"]), float(z["weight_decay"]), int(z["n_steps"])
@@ -61,8 +68,8 @@ def test_oracle_trainer_reproduces_hf_plus_adam_steps(case):
     tr = OracleTrainer(spec, seeded_checkpoint(spec, int(z["seed"])), lr=lr, weight_decay=wd, loss=loss_name)
     for st in range(n_steps):
         loss, logits, grads = tr.step(z[f"s{st}_ids"], z[f"s{st}_cu"], z[f"s{st}_labels"], z[f"s{st}_shuffle"])
-        assert abs(loss - float(z[f"s{st}_loss"])) <= 1e-5 * max(1.0, abs(float(z[f"s{st}_loss"]))), (case, st)
-        np.testing.assert_allclose(logits, z[f"s{st}_logits"], atol=2e-5, rtol=0)
+        assert abs(loss - float(z[f"s{st}_loss"])) <= (1e-5 if st == 0 else _after_update_tol(loss_name, 1e-5)) * max(1.0, abs(float(z[f"s{st}_loss"]))), (case, st)
+        np.testing.assert_allclose(logits, z[f"s{st}_logits"], atol=2e-5 if st == 0 else _after_update_tol(loss_name, 2e-5), rtol=0)
         if st == 0:
             for key in [k for k in z.files if k.startswith("grad0::")]:
                 name = key[len("grad0::"):]
@@ -108,8 +115,8 @@ def test_hip_training_steps_match_hf_plus_adam(case, precision):
         args = (z[f"s{st}_ids"], z[f"s{st}_cu"], z[f"s{st}_labels"], z[f"s{st}_shuffle"])
         loss, logits = tr.step(*args, return_logits=True)
         ref = float(z[f"s{st}_loss"])
-        assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)), (case, st, loss, ref)
-        np.testing.assert_allclose(logits, z[f"s{st}_logits"], atol=3e-5, rtol=0)
+        assert abs(loss - ref) <= (2e-5 if st == 0 else _after_update_tol(loss_name, 2e-5)) * max(1.0, abs(ref)), (case, st, loss, ref)
+        np.testing.assert_allclose(logits, z[f"s{st}_logits"], atol=3e-5 if st == 0 else _after_update_tol(loss_name, 3e-5), rtol=0)
         if st == 0:
             g = tr.grads()
             _, _, og = orc.step(*args, apply=False)
@@ -213,13 +220,22 @@ def test_hip_trainer_learns_and_round_trips_through_the_serving_path(tmp_path):
 @pytest.mark.gpu
 def test_fit_loop_with_kendall_tau_and_refused_losses():
     """fit() = the loop of train/trainer.py:134-200: shuffled slates per epoch, then the evaluation pass (eval-mode
-    forward, Kendall's tau of the predictions against the labels, :195).  neuralNDCG (:127) is refused by name."""
+    forward, Kendall's tau of the predictions against the labels, :195).  An unknown loss is refused by name; neuralNDCG
+    (:127) stops before the step on labels whose 2^label gain is inf (the reference trains to NaN there)."""
     from vllm_ltr_amd.opt_spec import OPTSpec
     from vllm_ltr_amd.trainer import HipPredictorTrainer, len2label
     spec = OPTSpec.tiny_pre_ln()
     ckpt = seeded_checkpoint(spec, 78)
-    with pytest.raises(NotImplementedError, match="neuralNDCG"):
-        HipPredictorTrainer(spec, ckpt, "cuda:0", loss="neuralNDCG")
+    with pytest.raises(ValueError, match="approxNDCG"):
+        HipPredictorTrainer(spec, ckpt, "cuda:0", loss="approxNDCG")
+    nd = HipPredictorTrainer(spec, ckpt, "cuda:0", loss="neuralNDCG")
+    ids3, cu3 = np.array([2, 5, 9, 2, 7, 2, 11, 12], np.int64), np.array([0, 3, 5, 8], np.int32)
+    with pytest.raises(ValueError, match="overflows f32"):
+        nd.step(ids3, cu3, [3.0, 128.0, 1.0])                  # ungrouped trainer labels reach 8192
+    with pytest.raises(ValueError, match="2..1024"):
+        nd.step(ids3[:3], cu3[:2], [3.0])                      # the reference: IndexError (loss_utils.py:70)
+    assert np.isfinite(nd.step(ids3, cu3, [3.0, 127.0, 1.0]))
+    nd.close()
     r = np.random.RandomState(0)
 
     def example():

@@ -24,10 +24,11 @@ SYMBOLS = ("ltr_abi_version", "ltr_last_error", "ltr_create", "ltr_destroy", "lt
            "ltr_set_chunk_tokens", "ltr_score", "ltr_forward_hidden", "ltr_embed_gather", "ltr_pool_head",
            "ltr_rank_step", "ltr_age_update", "ltr_budget_prefix", "ltr_profile_enable", "ltr_profile_read",
            "ltr_head_create", "ltr_head_destroy", "ltr_head_score", "ltr_reserve_select", "ltr_listmle",
+           "ltr_neuralndcg", "ltr_neuralndcg_workspace_bytes",
            "ltr_status", "ltr_queue_step", "ltr_train_create", "ltr_train_destroy", "ltr_train_workspace_bytes",
            "ltr_train_step", "ltr_train_read", "ltr_attention", "ltr_train_attention",
            "ltr_train_attention_workspace_bytes")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 LTR_E_INVAL, LTR_E_RANGE = -22, -34
@@ -65,7 +66,7 @@ class TrainConfig(C.Structure):
                 ("dropout", C.c_float), ("precision", C.c_int32), ("seed", C.c_uint64)]
 
 
-LOSSES = {"listMLE": 0, "mse": 1, "crossentropy": 2}
+LOSSES = {"listMLE": 0, "mse": 1, "crossentropy": 2, "neuralNDCG": 3}
 TRAIN_PRECISIONS = {None: 0, "split": 1, "f32": 2}
 
 
@@ -122,6 +123,9 @@ def _load() -> C.CDLL:
     lib.ltr_profile_read.argtypes = [vp, C.POINTER(ProfileStats), i32]
     lib.ltr_reserve_select.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, C.c_int64, vp, vp, vp, vp]
     lib.ltr_listmle.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp]
+    lib.ltr_neuralndcg.argtypes = [vp, vp, i32, i32, C.c_float, i32, C.c_float, vp, vp, vp, vp, sz, vp]
+    lib.ltr_neuralndcg_workspace_bytes.argtypes = [i32, i32]
+    lib.ltr_neuralndcg_workspace_bytes.restype = sz
     lib.ltr_head_create.argtypes = [C.POINTER(HeadDesc), C.POINTER(vp), i32, C.POINTER(vp)]
     lib.ltr_head_destroy.argtypes = [vp]
     lib.ltr_head_score.argtypes = [vp, vp, vp, i32, vp, vp]
@@ -137,7 +141,7 @@ def _load() -> C.CDLL:
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ltr_last_error", "ltr_workspace_bytes", "ltr_abi_version", "ltr_train_workspace_bytes",
-                        "ltr_train_attention_workspace_bytes"):
+                        "ltr_train_attention_workspace_bytes", "ltr_neuralndcg_workspace_bytes"):
             fn.restype = C.c_int
     if lib.ltr_abi_version() != ABI_VERSION:
         raise LtrError(f"{LIB_PATH} has ABI version {lib.ltr_abi_version()}, this binding needs {ABI_VERSION}: rebuild")

@@ -13,7 +13,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["ltr_api.hip", "ltr_rank.hip", "ltr_rows.hip", "ltr_gemm.hip", "ltr_attn.hip", "ltr_pool.hip", "ltr_head.hip", "ltr_train.hip", "ltr_trainer.hip"]
+SOURCES = ["ltr_api.hip", "ltr_rank.hip", "ltr_rows.hip", "ltr_gemm.hip", "ltr_attn.hip", "ltr_pool.hip", "ltr_head.hip", "ltr_train.hip", "ltr_ndcg.hip", "ltr_trainer.hip"]
 HEADERS = ["ltr_internal.h", os.path.join("..", "..", "include", "ltr_hip.h")]
 LIB = os.path.join(HERE, "libltr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -650,6 +650,8 @@ struct TrainWs {
   float *dh, *dbig, *dsmall, *dsmall2, *xhd, *t1, *t2, *partial, *Dq;
   float *opa, *wb;         // split-fp16 GEMM operands of one call: A image hi|lo over 2K, [Bh | Bl] weight image
   float *qkvp, *aop;       // hi | lo planes of qkv [2][T, 3H] and of the attention output [2][T, H] (fp16 path)
+  float* ndcg;             // scratch of the NeuralNDCG loss (ltr_neuralndcg): the unrolled Sinkhorn rounds of one slate
+  size_t ndcg_bytes;
   float *gtmp, *scales;    // partial products of a split-K weight-gradient GEMM; max |x| slots of the GEMM operands of the step
   int32_t* blk;
   int32_t* blk2;     // work list of the MFMA attention forward (fp16 path)
@@ -657,7 +659,7 @@ struct TrainWs {
   size_t bytes;
 };
 
-TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, bool dropout) {
+TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, bool dropout, bool ndcg) {
   const size_t H = d.hidden_size, F = d.ffn_dim, De = d.word_embed_proj_dim, nh = d.num_heads, nl = d.num_labels;
   const size_t Tp = (T + 127) / 128 * 128, Np = (N + 127) / 128 * 128;   // (contraction dims of the weight-gradient GEMMs, padded)
   const size_t big = std::max<size_t>(3 * H, F);
@@ -673,7 +675,10 @@ TrainWs carve_train(const ltr_model_desc& d, int64_t T, int64_t N, void* base, b
   }
   w.tok = take(T * De); w.hfin = take(T * H);
   w.hl = take(Np * H); w.z = take(Np * H); w.y = take(Np * De); w.logits = take(N * nl); w.dlogits = take(N * nl);
-  w.row_loss = take(N + 8); w.dy = take(Np * De); w.dz = take(Np * H); w.dhl = take(Np * H);
+  w.row_loss = take(N + 8);
+  w.ndcg_bytes = ndcg ? ltr_neuralndcg_workspace_bytes(1, (int32_t)std::min<int64_t>(N, 1 << 20)) : 0;   // 0 beyond its slate limit: the step refuses
+  w.ndcg = take(w.ndcg_bytes / 4);
+  w.dy = take(Np * De); w.dz = take(Np * H); w.dhl = take(Np * H);
   w.dh = take(T * H); w.dbig = take(T * big); w.dsmall = take(T * H); w.dsmall2 = take(T * H); w.xhd = take(T * H);
   w.t1 = take(big * Tp); w.t2 = take(big * Tp);
   w.qkvp = take(T * 3 * H + 64); w.aop = take(T * H + 64);           // 2 planes x 2 B = one float per element
@@ -1070,11 +1075,11 @@ int ltr_train_create(const ltr_model_desc* desc, const void* const* weights, int
     set_error("ltr_train_create: head size must be 64; F and De multiples of 64");
     return LTR_E_INVAL;
   }
-  if (cfg->loss != LTR_LOSS_LISTMLE && cfg->loss != LTR_LOSS_MSE && cfg->loss != LTR_LOSS_CROSSENTROPY) {
+  if (cfg->loss != LTR_LOSS_LISTMLE && cfg->loss != LTR_LOSS_MSE && cfg->loss != LTR_LOSS_CROSSENTROPY && cfg->loss != LTR_LOSS_NEURALNDCG) {
     set_error("ltr_train_create: unknown loss %d", cfg->loss); return LTR_E_INVAL;
   }
   if (cfg->loss != LTR_LOSS_CROSSENTROPY && d.num_labels != 1) {
-    set_error("ltr_train_create: listMLE / mse train a 1-label (rank) head (prefill_predictor.py:35-36)"); return LTR_E_INVAL;
+    set_error("ltr_train_create: listMLE / neuralNDCG / mse train a 1-label (rank) head (prefill_predictor.py:35-36)"); return LTR_E_INVAL;
   }
   if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) { set_error("ltr_train_create: dropout must be in [0, 1)"); return LTR_E_INVAL; }
   if (cfg->precision < LTR_TRAIN_PREC_DEFAULT || cfg->precision > LTR_TRAIN_PREC_F32) {
@@ -1133,7 +1138,7 @@ int ltr_train_destroy(ltr_train_handle h) {
 
 size_t ltr_train_workspace_bytes(ltr_train_handle h, int64_t N, int64_t T) {
   if (!h || N <= 0 || T <= 0) return 0;
-  return carve_train(h->d, T, N, nullptr, h->cfg.dropout > 0.f).bytes;
+  return carve_train(h->d, T, N, nullptr, h->cfg.dropout > 0.f, h->cfg.loss == LTR_LOSS_NEURALNDCG).bytes;
 }
 
 int ltr_train_read(ltr_train_handle h, int32_t index, int32_t what, float* dst, size_t capacity, size_t* count_out,
@@ -1163,9 +1168,13 @@ int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* 
     if (L <= 0 || L > d.pos_rows - 2) { set_error("ltr_train_step: request %d has %d tokens (1..%d allowed)", r, L, d.pos_rows - 2); return LTR_E_INVAL; }
   }
   if (apply_update >= 0 && h->cfg.loss == LTR_LOSS_LISTMLE && (!shuffle || N > 4096)) { set_error("ltr_train_step: listMLE needs the shuffle permutation and a slate of at most 4096"); return LTR_E_INVAL; }
+  if (apply_update >= 0 && h->cfg.loss == LTR_LOSS_NEURALNDCG && (N < 2 || ltr_neuralndcg_workspace_bytes(1, N) == 0)) {
+    set_error("ltr_train_step: neuralNDCG takes a slate of 2..1024 prompts (one item: the reference raises IndexError, loss_utils.py:70)");
+    return LTR_E_INVAL;
+  }
   DevGuard guard(h->device);
   hipStream_t s = (hipStream_t)stream;
-  Ctx c{h, s, carve_train(d, T, N, workspace, h->cfg.dropout > 0.f), T, N};
+  Ctx c{h, s, carve_train(d, T, N, workspace, h->cfg.dropout > 0.f, h->cfg.loss == LTR_LOSS_NEURALNDCG), T, N};
   c.eval = apply_update < 0;
   if (!h->use_f32 && c.ws.bytes <= ws_bytes) LTR_HIP_CHECK(hipMemsetAsync(c.ws.scales, 0, MAX_GEMMS * 2 * sizeof(float), s));
   if (c.ws.bytes > ws_bytes) { set_error("ltr_train_step: workspace too small (%zu < %zu)", ws_bytes, c.ws.bytes); return LTR_E_NOMEM; }
@@ -1177,6 +1186,10 @@ int ltr_train_step(ltr_train_handle h, const int64_t* token_ids, const int32_t* 
   if (h->cfg.loss == LTR_LOSS_LISTMLE) {       // trainer.py:157: loss_func(outputs.view(1, -1), labels) - the batch is one slate
     rc = ltr_listmle(c.ws.logits, labels, shuffle, 1, N, h->cfg.listmle_eps, h->cfg.pad_value, loss_out, c.ws.row_loss,
                      c.ws.dlogits, stream);
+    if (rc) return rc;
+  } else if (h->cfg.loss == LTR_LOSS_NEURALNDCG) {   // trainer.py:127-128,157: neuralNDCG(outputs.view(1, -1), labels), every keyword at its default
+    rc = ltr_neuralndcg(c.ws.logits, labels, 1, N, 1.f, 0, h->cfg.pad_value, loss_out, c.ws.row_loss, c.ws.dlogits, c.ws.ndcg,
+                        c.ws.ndcg_bytes, stream);
     if (rc) return rc;
   } else if (h->cfg.loss == LTR_LOSS_MSE) {
     mse_kernel<<<1, 256, 0, s>>>(c.ws.logits, labels, N, loss_out, c.ws.dlogits);

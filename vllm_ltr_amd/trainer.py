@@ -64,12 +64,6 @@ class HipPredictorTrainer:
         self.precision = precision or ("f32" if os.environ.get("LTR_TRAIN_F32", "")[:1] == "1" else "split")
         if not torch.cuda.is_available():
             raise _lib.LtrError("HipPredictorTrainer needs a ROCm GPU (no CPU fallback on the product path)")
-        if loss == "neuralNDCG":
-            raise NotImplementedError("loss 'neuralNDCG' (trainer.py:127-128, allrank/models/losses/neuralNDCG.py) is not built: "
-                                      "every recipe in train/train.sh uses listMLE or the class heads, and on the trainer's own "
-                                      "labels (label_max_length - length: up to 8192) the reference's neuralNDCG is NaN - its "
-                                      "2^label gain overflows f32 from label 128 on (checked against the reference's code); "
-                                      "use listMLE, mse or crossentropy")
         if loss not in _lib.LOSSES:
             raise ValueError(f"loss {loss!r}: one of {sorted(_lib.LOSSES)} (trainer.py:125-132)")
         self.lib = _lib.load()
@@ -128,7 +122,7 @@ class HipPredictorTrainer:
     def step(self, ids: np.ndarray, cu_seqlens: np.ndarray, labels: Sequence[float],
              shuffle: Optional[Sequence[int]] = None, apply_update: bool = True, return_logits: bool = False):
         """``ids`` int64 [T] / ``cu_seqlens`` int32 [N+1]: the slate of prompts (already truncated to max_length);
-        ``labels`` [N]; ``shuffle``: listMLE's random permutation (listMLE.py:33; drawn here when None).
+        ``labels`` [N] (neuralNDCG: every label below 128); ``shuffle``: listMLE's random permutation (listMLE.py:33; drawn here when None).
         Returns the loss (float) [and the logits [N, num_labels] before the update]."""
         cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
         N, T = cu.shape[0] - 1, int(cu[-1])
@@ -147,6 +141,16 @@ class HipPredictorTrainer:
                 raise ValueError(f"crossentropy label {lab[i]!r} of prompt {i} is not a class index in "
                                  f"[0, {self.spec.num_labels}) (len2label with a mismatched label_max_length / "
                                  "label_group_size produces such labels; trainer.py:50-52,151)")
+        if self.loss == "neuralNDCG":
+            # neuralNDCG.py:62-64 gains are 2^label - 1 in f32: from label 128 on they are inf and the reference's loss - and,
+            # one Adam step later, every weight - is NaN.  ltr_neuralndcg computes exactly that; the trainer stops before it.
+            if N < 2 or N > 1024:
+                raise ValueError(f"neuralNDCG takes a slate of 2..1024 prompts, not {N} (one item: the reference raises "
+                                 "IndexError, loss_utils.py:70)")
+            if lab.max() >= 128:
+                raise ValueError(f"neuralNDCG label {lab.max():.0f}: 2^label overflows f32 from 128 on and the loss is NaN, in "
+                                 "the reference too (neuralNDCG.py:62-64) - bucket the lengths (--label-group-size >= 65 for "
+                                 "label_max_length 8192, trainer.py:50-52)")
         lab_d = torch.from_numpy(lab).to(dev)
         sh_d = None
         if self.loss == "listMLE":
