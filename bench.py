@@ -272,11 +272,13 @@ def run_train(args, spec, ckpt, dev):
     from vllm_ltr_amd.trainer import HipPredictorTrainer
     n = args.train_slate
     ids, cu, lens = synthetic_queue(spec, n, seed=0, profile=args.profile)
-    labels = np.random.RandomState(1).permutation(n).astype(np.float32)
+    labels = np.random.RandomState(1).permutation(n).astype(np.float32)      # (neuralNDCG: 2^label gains, labels must stay < 128)
+    if args.train_loss == "neuralNDCG":
+        labels = labels % 83                                                 # --label-group-size 100 (train.sh): labels 0..82
     sh = np.random.RandomState(2).permutation(n)
 
     def timed(precision):
-        tr = HipPredictorTrainer(spec, ckpt, str(dev), lr=2e-5, weight_decay=0.01, loss="listMLE", precision=precision)
+        tr = HipPredictorTrainer(spec, ckpt, str(dev), lr=2e-5, weight_decay=0.01, loss=args.train_loss, precision=precision)
         for _ in range(args.warmup):
             tr.step(ids, cu, labels, shuffle=sh)
         torch.cuda.synchronize()
@@ -291,13 +293,13 @@ def run_train(args, spec, ckpt, dev):
     dt32 = timed("f32")[0] if args.train_precision == "both" else None
     dt, loss = timed("split")
     lin, att = model_flops(spec, lens)
-    out = {"metric": "fine-tuning step of the predictor (forward + listMLE + backward + Adam), tokens/s",
+    out = {"metric": f"fine-tuning step of the predictor (forward + {args.train_loss} + backward + Adam), tokens/s",
            "value": float(cu[-1]) / dt, "unit": "tokens/s", "higher_is_better": True, "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3,
            "dtype": "f32 master weights / activations / gradients; GEMMs split-fp16 x split-fp16 MFMA (4 passes), f32 accumulate",
            "exact_f32_ms_per_step": dt32 * 1e3 if dt32 else None, "speedup_vs_exact_f32": dt32 / dt if dt32 else None,
            "data": "synthetic (seeded random-init OPT checkpoint, lognormal prompt lengths)",
-           "config": {"workload": f"OPT-{args.model} predictor, slate of {n} prompts ({int(cu[-1])} tokens), listMLE, Adam"},
+           "config": {"workload": f"OPT-{args.model} predictor, slate of {n} prompts ({int(cu[-1])} tokens), {args.train_loss}, Adam"},
            "algorithmic_tflops": 3.0 * (lin + att) / dt / 1e12, "loss": loss}
     print(json.dumps(out))
 
@@ -347,6 +349,7 @@ def main():
     ap.add_argument("--trace", default=None, choices=["burst", "gamma"], help="config 5 ranker-side trace replay")
     ap.add_argument("--train", action="store_true", help="time the fine-tuning step instead (SURVEY 8f-4)")
     ap.add_argument("--train-slate", type=int, default=32)
+    ap.add_argument("--train-loss", default="listMLE", choices=["listMLE", "neuralNDCG"], help="trainer.py --loss (ranking losses)")
     ap.add_argument("--train-precision", default="both", choices=["both", "split"],
                     help="both: also time the exact-f32 path for comparison; split: the product path only (profiling)")
     ap.add_argument("--prescore", action="store_true", help="trace replay: score requests when they arrive (MI355XRanker(prescore=True))")

@@ -14,7 +14,8 @@
 //
 // Shape of the work: a slate is a training batch (trainer.py --batch-size 32), the matrices are n x n, every pass over them is
 // a dependent step: latency-bound VALU work, one 256-thread workgroup per slate, matrices in the caller's workspace (L2
-// resident), vectors in LDS.  Four launches: forward (sort + all 50 rounds, each round's residual recorded), value (picks the
+// resident), vectors in LDS.  (Keeping the working matrix in LDS as well was tried: 1,027 -> 982 us for a slate of 32 - the time
+// is the 50 x 2 chain of wave reductions, divisions and barriers, not the loads - and dropped.)  Four launches: forward (sort + all 50 rounds, each round's residual recorded), value (picks the
 // batch-wide stopping round, NDCG and ideal DCG per slate), mean (loss, number of live slates), backward.
 // All sums run in a fixed order: results are reproducible run to run.
 #include "ltr_internal.h"
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(ND_THREADS) ndcg_forward_kernel(const float* _
 __device__ int rounds_run(const float* __restrict__ ws, int B, int S) {
   for (int t = 0; t < ND_ROUNDS; ++t) {
     bool ok = true;
-    for (int b = 0; b < B && ok; ++b) ok = nd_carve(const_cast<float*>(ws), b, S).res[t] < ND_TOL;
+    for (int b = 0; b < B && ok; ++b) ok = (ws + (size_t)b * nd_slate_floats(S) + (size_t)(2 * ND_ROUNDS + 3) * S * S)[t] < ND_TOL;
     if (ok) return t + 1;
   }
   return ND_ROUNDS;
@@ -178,11 +179,10 @@ __global__ void __launch_bounds__(ND_THREADS) ndcg_value_kernel(const float* __r
   __shared__ float red[ND_WAVES];
   const Slate L = slate_lds(lds, S);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const NdWs W = nd_carve(const_cast<float*>(ws), b, S);
   (void)load_slate(L, y_true, y_true, b, S, pad_value, red);               // predictions are not needed here
   __syncthreads();
   const int rounds = rounds_run(ws, B, S);
-  const float* Fm = W.mats + (size_t)(2 * rounds) * S * S;
+  const float* Fm = ws + (size_t)b * nd_slate_floats(S) + (size_t)(2 * rounds) * S * S;
   for (int c = tid; c < S; c += ND_THREADS) L.v0[c] = exp2f(L.lab[c]) - 1.f;         // neuralNDCG.py:62-64 (padded: 2^0 - 1)
   __syncthreads();
   float dcg = 0.f;
