@@ -136,6 +136,38 @@ def test_hip_training_steps_match_hf_plus_adam(case, precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("loss", ["listMLE", "neuralNDCG"])
+def test_training_steps_are_bit_reproducible(loss):
+    """Every reduction of the step runs in a fixed order - split-K parts in part order, the embedding-table gradients summed in
+    token order by one owner (no float atomics), dropout masks from a counter hash - so two trainers fed the same slates end
+    with the same bits.  Slates with heavy duplication: every prompt starts with token 2, half the tokens come from 8 ids."""
+    from vllm_ltr_amd.opt_spec import OPTSpec
+    from vllm_ltr_amd.trainer import HipPredictorTrainer
+    spec = OPTSpec.tiny_pre_ln()
+    ckpt = seeded_checkpoint(spec, 80)
+    r = np.random.RandomState(9)
+    slates = []
+    for _ in range(4):
+        toks = [[2] + [int(x) for x in np.where(r.rand(L) < 0.5, r.randint(4, 12, L), r.randint(12, spec.vocab_size, L))]
+                for L in r.randint(1, 60, 24)]
+        slates.append((toks, r.randint(0, 40, 24).astype(np.float32), r.permutation(24)))
+
+    def run():
+        tr = HipPredictorTrainer(spec, ckpt, "cuda:0", lr=1e-3, weight_decay=0.01, loss=loss, dropout=0.1, seed=7)
+        losses = [tr.step_lists(t, y, shuffle=sh) for t, y, sh in slates]
+        g, w = tr.grads(), tr.state()
+        tr.close()
+        return losses, g, w
+    a, b = run(), run()
+    assert a[0] == b[0]
+    for name in a[1]:
+        assert np.array_equal(a[1][name], b[1][name]), f"gradient of {name} differs between two identical runs"
+        assert np.array_equal(a[2][name], b[2][name]), f"{name} differs after four identical steps"
+    emb = a[1]["model.decoder.embed_tokens.weight"]
+    assert np.abs(emb[2]).max() > 0 and np.abs(emb[4:12]).max() > 0       # the duplicated rows did receive their sums
+
+
+@pytest.mark.gpu
 def test_gradient_only_calls_do_not_advance_adam_and_bad_class_labels_raise():
     """torch.optim.Adam advances its step count in optimizer.step() only: a gradient-only call (apply_update=False,
     what grads() users make) must leave the bias corrections of the next real update untouched.  And a crossentropy
