@@ -83,7 +83,7 @@ def _build_tools(force: bool) -> None:
         exe = os.path.join(out_dir, name)
         deps = [os.path.join(HERE, src), LIB] + [os.path.join(HERE, h) for h in HEADERS]
         if force or _stale(exe, deps):
-            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-I" + HERE,
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-pthread", "-Wno-unused-result", "-I" + HERE,
                    "-I" + os.path.join(HERE, "..", "..", "include"), os.path.join(HERE, src), "-L" + HERE, "-lltr_hip",
                    "-Wl,-rpath,$ORIGIN/..", "-o", exe]
             r = subprocess.run(cmd, capture_output=True, text=True)

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <vector>
 #include <hip/hip_fp16.h>
 #include "ltr_internal.h"
@@ -18,6 +20,27 @@ using namespace ltr;
 static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
 template <class T> T* dev(const std::vector<T>& v) { T* p; (void)hipMalloc(&p, v.size() * sizeof(T)); (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return p; }
 template <class T> std::vector<T> host(const T* p, size_t n) { std::vector<T> v(n); (void)hipMemcpy(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost); return v; }
+
+// The host reference is a scalar triple loop; its rows are independent: row ranges on up to 32 host threads
+// (GEMM_CHECK_THREADS overrides).  body(m_begin, m_end, counters of this thread); the counters are summed afterwards, the
+// "first few" printouts are per thread.
+struct Bad { int out = 0, ln = 0, st = 0, c = 0; };
+static Bad over_rows(int M, const std::function<void(int, int, Bad&)>& body) {
+  const char* e = getenv("GEMM_CHECK_THREADS");
+  int nt = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  nt = nt < 1 ? 1 : (nt > 32 ? 32 : nt);
+  if (nt > M) nt = M;
+  std::vector<Bad> bad(nt);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) {
+    const int m0 = (int)((long long)M * t / nt), m1 = (int)((long long)M * (t + 1) / nt);
+    th.emplace_back([&, t, m0, m1] { body(m0, m1, bad[t]); });
+  }
+  for (auto& x : th) x.join();
+  Bad s;
+  for (auto& b : bad) { s.out += b.out; s.ln += b.ln; s.st += b.st; s.c += b.c; }
+  return s;
+}
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 200, N = argc > 2 ? atoi(argv[2]) : 128, K = argc > 3 ? atoi(argv[3]) : 128;
@@ -54,8 +77,9 @@ int main(int argc, char** argv) {
   auto ln = host(d_ln, (size_t)M * N * 2);
   auto st = host(d_stats, (size_t)(N / 64) * M);
   std::vector<double> ref((size_t)M * N);
-  int bad_out = 0, bad_ln = 0, bad_st = 0;
-  for (int m = 0; m < M; ++m) {
+  const Bad bp = over_rows(M, [&](int mb, int me, Bad& bd) {
+  int &bad_out = bd.out, &bad_ln = bd.ln, &bad_st = bd.st;
+  for (int m = mb; m < me; ++m) {
     for (int n = 0; n < N; ++n) {
       double s = 0;
       for (int k = 0; k < K; ++k) s += ((double)__half2float(ahi[(size_t)m * K + k]) + (double)__half2float(alo[(size_t)m * K + k])) * (double)__half2float(w[(size_t)n * K + k]);
@@ -81,6 +105,8 @@ int main(int argc, char** argv) {
       if (!(fabs(s2.x - mu) <= 1e-4) || !(fabs(s2.y - q) <= 1e-3 * (1 + q))) { if (bad_st++ < 12) printf("stats[piece %d, row %d] = (%g, %g) want (%g, %g)\n", p, m, s2.x, s2.y, mu, q); }
     }
   }
+  });
+  const int bad_out = bp.out, bad_ln = bp.ln, bad_st = bp.st;
   printf("LNP: bad out %d, bad a' %d, bad stats %d\n", bad_out, bad_ln, bad_st);
 
   // consumer: A = a' planes (slab-major), stats; W2 [N2, N]; expected = LN(ref) W2^T + b2 with LN affine (gamma, beta)
@@ -105,8 +131,9 @@ int main(int argc, char** argv) {
   (void)hipDeviceSynchronize();
   printf("LNC rc=%d\n", rc);
   auto o2 = host(d_o2, (size_t)M * N2 * 2);
-  int bad_c = 0;
-  for (int m = 0; m < M; ++m) {
+  const Bad bc = over_rows(M, [&](int mb, int me, Bad& bd) {
+  int& bad_c = bd.c;
+  for (int m = mb; m < me; ++m) {
     if (!inside(m)) {
       for (int n2 = 0; n2 < N2; ++n2) {
         unsigned short raw; memcpy(&raw, &o2[(size_t)m * N2 + n2], 2);
@@ -126,6 +153,8 @@ int main(int argc, char** argv) {
       if (!(fabs(got - s) <= 1e-3 * (1 + fabs(s)))) { if (bad_c++ < 12) printf("lnc[%d,%d] = %g want %g\n", m, n2, got, s); }
     }
   }
+  });
+  const int bad_c = bc.c;
   printf("LNC: bad %d of %d\n", bad_c, M * N2);
   return (bad_out || bad_ln || bad_st || bad_c) ? 1 : 0;
 }
