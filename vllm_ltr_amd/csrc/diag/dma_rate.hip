@@ -3,6 +3,8 @@
 //   mode 1: global_load_lds_dword   (LDS DMA, 256 B per wave instruction)
 //   mode 2: global_load_dwordx4 into registers (1 KiB per wave instruction)
 //   mode 3: mode 2 followed by ds_write_b128 (register staging)
+//   mode 4: batches of DEPTH LDS-DMA loads + DEPTH register loads in flight together (does the register path add to what a CU
+//           pulls, or do both queue behind the same limit?)      mode 5: batches of 2 x DEPTH LDS-DMA loads (its baseline)
 // Every wave walks 1-KiB chunks of a buffer small enough to stay in L2 (per XCD), keeping DEPTH
 // loads in flight.  Output: GB/s chip-wide and per CU.
 #include <hip/hip_runtime.h>
@@ -18,7 +20,7 @@ __global__ void __launch_bounds__(512) rate_kernel(const char* __restrict__ buf,
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const size_t gw = (size_t)blockIdx.x * nw + wave;
-  char* my = lds + wave * DEPTH * 1024;
+  char* my = lds + wave * DEPTH * 1024 * (MODE >= 4 ? 2 : 1);
   uint4 acc = make_uint4(0, 0, 0, 0);
   const size_t nchunk = buf_bytes / 1024;
   // stride_rows == 0: 1 KiB contiguous per instruction; otherwise 16 rows x 64 B with a row pitch
@@ -29,7 +31,23 @@ __global__ void __launch_bounds__(512) rate_kernel(const char* __restrict__ buf,
     const size_t base = (c * 1024) & (buf_bytes / 2 - 1);
     return buf + (base & ~(size_t)63) + (size_t)(lane >> 2) * stride_rows + (lane & 3) * 16;
   };
-  if (MODE >= 2) {
+  if (MODE == 4 || MODE == 5) {
+    for (int it = 0; it < iters; it += 2 * DEPTH) {
+      uint4 v[DEPTH];
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) __builtin_amdgcn_global_load_lds((gbl_void*)src(it + d), (lds_void*)(my + d * 1024), 16, 0, 0);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        if (MODE == 4) v[d] = *reinterpret_cast<const uint4*>(src(it + DEPTH + d));
+        else __builtin_amdgcn_global_load_lds((gbl_void*)src(it + DEPTH + d), (lds_void*)(my + (DEPTH + d) * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (MODE == 4) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) { acc.x ^= v[d].x; acc.y ^= v[d].y; acc.z ^= v[d].z; acc.w ^= v[d].w; }
+      }
+    }
+  } else if (MODE >= 2) {
     for (int it = 0; it < iters; it += DEPTH) {
       uint4 v[DEPTH];
 #pragma unroll
@@ -69,7 +87,7 @@ template <int MODE, int DEPTH>
 static void run(const char* name, const char* buf, size_t buf_bytes, int blocks_per_cu, int waves, int stride_rows, unsigned* sink) {
   const int iters = 2000;
   const int grid = 256 * blocks_per_cu;
-  const size_t lds = (size_t)waves * DEPTH * 1024;
+  const size_t lds = (size_t)waves * DEPTH * 1024 * (MODE >= 4 ? 2 : 1);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   rate_kernel<MODE, DEPTH><<<grid, waves * 64, lds>>>(buf, buf_bytes, 200, stride_rows, sink);
@@ -87,6 +105,20 @@ int main(int argc, char** argv) {
   const size_t max_bytes = (size_t)1 << 30;
   char* buf; unsigned* sink;
   (void)hipMalloc(&buf, max_bytes); (void)hipMemset(buf, 1, max_bytes); (void)hipMalloc(&sink, 64);
+  if (argc > 1) {      // dma_rate mix: the mixed-path question only, L2-resident / Infinity-Cache-resident / HBM buffers
+    for (size_t mb : {2, 64, 1024}) {
+      const size_t bb = mb << 20;
+      for (int bpc : {1, 2}) {
+        run<5, 4>("dma+dma", buf, bb, bpc, 4, 0, sink);
+        run<4, 4>("dma+reg", buf, bb, bpc, 4, 0, sink);
+        run<5, 6>("dma+dma", buf, bb, bpc, 4, 0, sink);
+        run<4, 6>("dma+reg", buf, bb, bpc, 4, 0, sink);
+        run<2, 8>("reg128", buf, bb, bpc, 4, 0, sink);
+        run<2, 12>("reg128", buf, bb, bpc, 4, 0, sink);
+      }
+    }
+    return 0;
+  }
   for (size_t mb : {1, 2, 16}) {
     const size_t bb = mb << 20;
     for (int pitch : {0, 1536}) {
