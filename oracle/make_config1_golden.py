@@ -38,6 +38,10 @@ structure of TRAINED OPT weights (``opt_spec.structured_checkpoint``: 5x init sc
 (``opt``, no starvation) the reference's own Scheduler returns for those scores.  ``--config outlier350``: the same for the
 OPT-350m shape (post-LN blocks, project_in / project_out; 48 requests) -> ``tests/golden/outlier_opt350m_48.npz``.
 
+``--config 2`` writes ``tests/golden/config2_opt125m_8192.npz``: BASELINE config 2 at FULL size (8,192 requests, 708,977 tokens) as one
+cold step of the reference's Scheduler + fp32 predictor: all 8,192 reference scores and the order (see ``main_config2``);
+``--config 3full`` the same for BASELINE config 3 (OPT-350m, 8,192 LMSYS-like requests) -> ``tests/golden/config3_opt350m_8192.npz``.
+
 Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
 """
 from __future__ import annotations
@@ -280,6 +284,42 @@ def main_config3():
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def main_config2(which="2"):
+    """(``which`` = "3full": BASELINE config 3 at full size instead - OPT-350m, 8,192 LMSYS-like requests, 1,407,401 tokens - into
+    ``tests/golden/config3_opt350m_8192.npz``; ~35 min on 8 cores.)
+    BASELINE config 2 at FULL size - the headline workload: OPT-125m, 8,192 requests, 708,977 tokens - as ONE cold step of the
+    reference's own Scheduler (``opt-xxx-starv200-period10``): every request is scored by the reference's fp32 predictor in the AUX
+    engine's FCFS packs (one ``obtain_aux_scores`` call), then ordered by ``_get_ordered_requests``.  The fixture holds the 8,192
+    reference scores, the order, the budget-walk inputs / grants of that step and a SHA-256 of the token ids (the queue itself is
+    ``bench.synthetic_queue(spec, 8192, seed 0)``: regenerated by the test, not stored).  ~25 min on 8 cores."""
+    import hashlib
+    mg._init_dist()
+    torch.set_num_threads(os.cpu_count())
+    n = 8192
+    full3 = which == "3full"
+    spec = OPTSpec.opt_350m() if full3 else OPTSpec.opt_125m()
+    ckpt = seeded_checkpoint(spec, 0)
+    ids, cu, lens = synthetic_queue(spec, n, seed=0, profile="lmsys") if full3 else synthetic_queue(spec, n, seed=0)
+    assert int(cu[-1]) == (1407401 if full3 else 708977), int(cu[-1])       # BASELINE.json configs[2] / configs[1]
+    out = dict(cu_seqlens=cu, seed=np.int64(0),
+               ids_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(ids.astype(np.int32)).tobytes()).digest(), np.uint8))
+    pred = RefPredictor(spec, ckpt)
+    t0 = time.time()
+    s_a, sgs_a, rec_a = run("a", "opt-xxx-starv200-period10", pred, ids, cu, np.zeros(n, np.int32), 1, 2048, 256, out)
+    scores = np.array([g.aux_model_score for g in sgs_a], np.float64)
+    assert np.isfinite(scores).all() and len(pred.calls) == 1 and len(pred.calls[0]) == n
+    out["ref_score"] = scores.astype(np.float32)
+    assert np.array_equal(out["ref_score"].astype(np.float64), scores)
+    gaps = np.diff(np.sort(scores))
+    print(f"config {'3' if full3 else '2'} (full size): T = {int(cu[-1])}, one predictor call of {n} requests, {pred.seconds:.1f} s in the reference "
+          f"predictor ({n / pred.seconds:.1f} req/s on {os.cpu_count()} threads), total {time.time()-t0:.1f} s; score range "
+          f"[{scores.min():.4f}, {scores.max():.4f}]; gaps between sorted scores: min {gaps.min():.3e}, "
+          f"{int((gaps < 2e-6).sum())} below 2e-6, {int((gaps == 0).sum())} exact ties")
+    path = os.path.join(GOLD, "config3_opt350m_8192.npz" if full3 else "config2_opt125m_8192.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main_tpt():
     """Config 1's queue under `tpt`: class-mode predictor (82 labels), order (-score, request_id) on string ids."""
     mg._init_dist()
@@ -384,6 +424,8 @@ def main():
         return main_xpt()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":
         return main_config3()
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] in ("2", "3full"):
+        return main_config2(sys.argv[sys.argv.index("--config") + 1])
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "tpt":
         return main_tpt()
     mg._init_dist()

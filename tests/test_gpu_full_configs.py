@@ -164,3 +164,71 @@ def test_config3_opt350m_8k_lmsys_like_queue_full_size():
     print(f"config 3 (OPT-350m, 8192 requests, {T} tokens, {len(passes)} passes): oracle sample of {len(sample)} "
           f"requests, max|d| = {err:.3e}")
     assert err <= TOL
+
+
+def _inversions_worst_gap(order_ref, order_got, score):
+    """(number of pairs the two orders rank differently, largest |score gap| among them) - numpy, for 8k-request orders."""
+    pos = np.empty(len(order_got), np.int64)
+    pos[np.asarray(order_got, np.int64)] = np.arange(len(order_got))
+    ref = np.asarray(order_ref, np.int64)
+    p = pos[ref]                                   # position in `got` of the i-th request of `ref`
+    sc = np.asarray(score, np.float64)[ref]
+    n_inv, worst = 0, 0.0
+    for i0 in range(0, len(ref), 512):
+        blk = p[i0:i0 + 512, None] > p[None, :]    # [i, j]: j sits before i in `got` ...
+        blk &= np.arange(len(ref))[None, :] > np.arange(i0, min(i0 + 512, len(ref)))[:, None]     # ... but after it in `ref`
+        if blk.any():
+            n_inv += int(blk.sum())
+            gaps = np.abs(sc[i0:i0 + 512, None] - sc[None, :])
+            worst = max(worst, float(gaps[blk].max()))
+    return n_inv, worst
+
+
+FULL_RUNS = {"config2": ("config2_opt125m_8192.npz", OPTSpec.opt_125m, 64.0, 708977),
+             "config3": ("config3_opt350m_8192.npz", OPTSpec.opt_350m, 128.0, 1407401)}
+
+
+@pytest.mark.parametrize("which", list(FULL_RUNS))
+def test_full_queue_against_the_reference_run(which):
+    """BASELINE configs 2 and 3 at FULL size against the REFERENCE itself (tests/golden/config2_opt125m_8192.npz /
+    config3_opt350m_8192.npz, written by oracle/make_config1_golden.py --config 2 / 3full: one cold step of the reference's
+    Scheduler with its fp32 predictor on all 8,192 requests): every HIP score within the north-star tolerance of the
+    reference's, the HIP sort of the REFERENCE's scores bit-identical to the reference's order, and the end-to-end order
+    (HIP scores -> HIP sort) differing from it only in fp32 near-ties."""
+    import hashlib
+    import os
+    from vllm_ltr_amd.rank import RankWorkspace, budget_prefix, rank_step
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    name, mk_spec, mu, tokens = FULL_RUNS[which]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), allow_pickle=False)
+    dev = torch.device("cuda:0")
+    spec = mk_spec()
+    ids, cu, lens = _queue(spec, 8192, mu)
+    assert int(cu[-1]) == tokens and np.array_equal(cu, z["cu_seqlens"])
+    assert hashlib.sha256(np.ascontiguousarray(ids.astype(np.int32)).tobytes()).digest() == z["ids_sha256"].tobytes()
+    ref = z["ref_score"]
+    want = z["a_order"][0]
+    assert (want >= 0).all() and sorted(want.tolist()) == list(range(8192))
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", "f16")
+    hip = sc.score(ids, cu)
+    err = np.abs(hip.astype(np.float64) - ref.astype(np.float64))
+    print(f"{which}, all 8,192 requests ({int(cu[-1]):,} tokens) against the reference's fp32 predictor: max|d| = {err.max():.3e}, "
+          f"rms {np.sqrt((err ** 2).mean()):.3e}")
+    assert err.max() <= TOL
+    ws = RankWorkspace(dev)
+    perm_ref = rank_step(torch.from_numpy(ref).to(dev), None, None, None, -1, 0, ws).cpu().numpy()
+    assert perm_ref.tolist() == want.tolist()                       # the reference's scores through the HIP sort: its order, bit for bit
+    perm = rank_step(torch.from_numpy(hip).to(dev), None, None, None, -1, 0, ws).cpu().numpy()
+    n_inv, worst = _inversions_worst_gap(want, perm, ref)
+    print(f"{which} END-TO-END order of the 8,192-request queue against the reference's: {n_inv} discordant pairs of "
+          f"{8192 * 8191 // 2}, largest reference-score gap among them {worst:.3e} (score error {err.max():.3e}; closest pair of "
+          f"reference scores {np.diff(np.sort(ref.astype(np.float64))).min():.3e})")
+    assert worst <= 2 * float(err.max())
+    # the budget walk of that step from the reference's order and needs: its selected prefix and grants
+    B, S = int(z["a_token_budget"]), int(z["a_max_num_seqs"])
+    t = lambda k, dt: torch.from_numpy(z[f"a_{k}"][0].astype(dt)).to(dev)
+    nsel, ran, granted = budget_prefix(torch.from_numpy(want.astype(np.int32)).to(dev), t("need_tokens", np.int32), t("need_seqs", np.int32),
+                                       B, S, chunkable=t("chunkable", np.uint8))
+    n = int(nsel.item())
+    assert sorted(want[:n].tolist()) == np.nonzero(z["a_ran"][0])[0].tolist()
+    assert granted.cpu().numpy()[want[:n]].tolist() == z["a_granted"][0][want[:n]].tolist()

@@ -225,6 +225,42 @@ def _config3():
 RECORDED = {"config1": (_config1, OPTSpec.opt_125m), "config3": (_config3, OPTSpec.opt_350m)}
 
 
+@pytest.mark.parametrize("name,mk_spec,profile,tokens", [("config2_opt125m_8192.npz", OPTSpec.opt_125m, "sharegpt", 708977),
+                                                         ("config3_opt350m_8192.npz", OPTSpec.opt_350m, "lmsys", 1407401)])
+def test_full_size_reference_runs(name, mk_spec, profile, tokens):
+    """BASELINE configs 2 and 3 at FULL size, run by the reference (one cold Scheduler step, its fp32 predictor on all 8,192 requests:
+    oracle/make_config1_golden.py --config 2 / 3full): the literal sort of the reference's scores is the reference's order of the whole
+    queue, bit for bit; the budget walk reproduces the step's grants; the oracle predictor agrees with the reference on requests
+    spread over the queue (shortest and longest included)."""
+    import hashlib
+    from bench import synthetic_queue
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    spec = mk_spec()
+    ids, cu, lens = synthetic_queue(spec, 8192, seed=0, profile=profile)
+    assert int(cu[-1]) == tokens and np.array_equal(cu, z["cu_seqlens"])
+    assert hashlib.sha256(np.ascontiguousarray(ids.astype(np.int32)).tobytes()).digest() == z["ids_sha256"].tobytes()
+    ref = z["ref_score"]
+    want = z["a_order"][0]
+    concat = z["a_concat"][0]
+    assert sorted(want.tolist()) == list(range(8192)) and concat.tolist() == list(range(8192))
+    reqs = [rs.Req(str(i), float(ref[i])) for i in range(8192)]
+    order = rs.opt_order(reqs, int(z["a_starv"]), int(z["a_period"]))
+    assert [int(r.request_id) for r in order] == want.tolist()
+    nsel, granted = rs.budget_walk(z["a_need_tokens"][0][want], z["a_need_seqs"][0][want], int(z["a_token_budget"]),
+                                   int(z["a_max_num_seqs"]), z["a_chunkable"][0][want])
+    assert set(want[:nsel].tolist()) == set(np.nonzero(z["a_ran"][0])[0].tolist())
+    assert granted == z["a_granted"][0][want[:nsel]].tolist()
+    pick = sorted({int(np.argmin(lens)), int(np.argmax(lens)), 0, 8191, int(want[0]), int(want[-1])} |
+                  set(np.random.RandomState(2).randint(0, 8192, 26 if spec.hidden_size == 768 else 10).tolist()))
+    ids_s = np.concatenate([ids[cu[i]:cu[i + 1]] for i in pick]).astype(np.int64)
+    cu_s = np.concatenate([[0], np.cumsum(lens[pick])]).astype(np.int32)
+    got = OracleOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"]))).score_packed(ids_s, cu_s)
+    err = float(np.abs(got - ref[pick]).max())
+    print(f"{name}: oracle vs the reference's predictor on {len(pick)} requests of the 8,192 (lengths "
+          f"{int(lens[pick].min())} ... {int(lens[pick].max())}): max|d| = {err:.3e}")
+    assert err <= 1e-5
+
+
 @pytest.mark.parametrize("which", list(RECORDED))
 def test_config1_oracle_scores_and_end_to_end_order(which):
     """The oracle predictor on config 1's whole queue (256 requests, 23,078 tokens; config 3's predictor: OPT-350m on 128
