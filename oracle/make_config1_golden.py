@@ -40,7 +40,9 @@ OPT-350m shape (post-LN blocks, project_in / project_out; 48 requests) -> ``test
 
 ``--config 2`` writes ``tests/golden/config2_opt125m_8192.npz``: BASELINE config 2 at FULL size (8,192 requests, 708,977 tokens) as one
 cold step of the reference's Scheduler + fp32 predictor: all 8,192 reference scores and the order (see ``main_config2``);
-``--config 3full`` the same for BASELINE config 3 (OPT-350m, 8,192 LMSYS-like requests) -> ``tests/golden/config3_opt350m_8192.npz``.
+``--config 3full`` the same for BASELINE config 3 (OPT-350m, 8,192 LMSYS-like requests) -> ``tests/golden/config3_opt350m_8192.npz``;
+``--config 4full`` for BASELINE config 4's queue (OPT-125m, 65,536 requests, 5,734,532 tokens: scores + order only) ->
+``tests/golden/config4_opt125m_65536.npz`` (~40 min on 8 cores).
 
 Nothing of the reference is copied: the fixture holds inputs and what the reference computed.
 """
@@ -295,12 +297,12 @@ def main_config2(which="2"):
     import hashlib
     mg._init_dist()
     torch.set_num_threads(os.cpu_count())
-    n = 8192
+    n = 65536 if which == "4full" else 8192
     full3 = which == "3full"
     spec = OPTSpec.opt_350m() if full3 else OPTSpec.opt_125m()
     ckpt = seeded_checkpoint(spec, 0)
     ids, cu, lens = synthetic_queue(spec, n, seed=0, profile="lmsys") if full3 else synthetic_queue(spec, n, seed=0)
-    assert int(cu[-1]) == (1407401 if full3 else 708977), int(cu[-1])       # BASELINE.json configs[2] / configs[1]
+    assert int(cu[-1]) == (1407401 if full3 else (5734532 if n == 65536 else 708977)), int(cu[-1])   # BASELINE.json configs[2] / [3] / [1]
     out = dict(cu_seqlens=cu, seed=np.int64(0),
                ids_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(ids.astype(np.int32)).tobytes()).digest(), np.uint8))
     pred = RefPredictor(spec, ckpt)
@@ -311,11 +313,17 @@ def main_config2(which="2"):
     out["ref_score"] = scores.astype(np.float32)
     assert np.array_equal(out["ref_score"].astype(np.float64), scores)
     gaps = np.diff(np.sort(scores))
-    print(f"config {'3' if full3 else '2'} (full size): T = {int(cu[-1])}, one predictor call of {n} requests, {pred.seconds:.1f} s in the reference "
+    print(f"config {'3' if full3 else ('4' if n == 65536 else '2')} (full size): T = {int(cu[-1])}, one predictor call of {n} requests, {pred.seconds:.1f} s in the reference "
           f"predictor ({n / pred.seconds:.1f} req/s on {os.cpu_count()} threads), total {time.time()-t0:.1f} s; score range "
           f"[{scores.min():.4f}, {scores.max():.4f}]; gaps between sorted scores: min {gaps.min():.3e}, "
           f"{int((gaps < 2e-6).sum())} below 2e-6, {int((gaps == 0).sum())} exact ties")
-    path = os.path.join(GOLD, "config3_opt350m_8192.npz" if full3 else "config2_opt125m_8192.npz")
+    if n == 65536:      # config 4: the scores and the order only (the per-request walk inputs are the prompt lengths)
+        out = {k: v for k, v in out.items() if k in ("seed", "ids_sha256", "ref_score", "a_order", "a_ran", "a_starv", "a_period",
+                                                     "a_token_budget", "a_max_num_seqs")}
+        out["a_ran"] = np.nonzero(out["a_ran"][0])[0].astype(np.int32)
+        out["cu_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(cu.astype(np.int32)).tobytes()).digest(), np.uint8)
+    path = os.path.join(GOLD, "config4_opt125m_65536.npz" if n == 65536 else
+                        ("config3_opt350m_8192.npz" if full3 else "config2_opt125m_8192.npz"))
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 
@@ -424,7 +432,7 @@ def main():
         return main_xpt()
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "3":
         return main_config3()
-    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] in ("2", "3full"):
+    if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] in ("2", "3full", "4full"):
         return main_config2(sys.argv[sys.argv.index("--config") + 1])
     if "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "tpt":
         return main_tpt()

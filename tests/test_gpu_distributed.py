@@ -306,6 +306,32 @@ def _worker_config4(rank, world, port, q):
             res["perm_ok"] = bool(np.array_equal(perm_h, rs.rank_step_np(scores, z.copy(), z.copy(), z.copy(), 200, 10)))
             wn, _ = rs.budget_walk(lens[perm_h], np.ones(n, np.int32), 2048, 256)
             res["budget_ok"] = wn == int(n_sel.item())
+            # ... and against the REFERENCE's own run of this queue (tests/golden/config4_opt125m_65536.npz: its Scheduler + fp32
+            # predictor on all 65,536 requests, oracle/make_config1_golden.py --config 4full): every gathered score, the HIP sort
+            # of the reference's scores, the end-to-end order up to fp32 near-ties, the selected prefix
+            zf = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_opt125m_65536.npz"), allow_pickle=False)
+            assert hashlib.sha256(np.ascontiguousarray(ids.astype(np.int32)).tobytes()).digest() == zf["ids_sha256"].tobytes()
+            assert hashlib.sha256(np.ascontiguousarray(cu.astype(np.int32)).tobytes()).digest() == zf["cu_sha256"].tobytes()
+            ref, want = zf["ref_score"], zf["a_order"][0].astype(np.int64)
+            err = np.abs(scores.astype(np.float64) - ref.astype(np.float64))
+            res["ref_err"], res["ref_rms"] = float(err.max()), float(np.sqrt((err ** 2).mean()))
+            q2 = DeviceQueue(dev, starv=200, period=10, capacity=n)
+            q2.append(torch.from_numpy(ref))
+            perm_ref, n_sel_ref, ran_ref, _ = q2.step(need, torch.ones(n, dtype=torch.int32, device=dev), 2048, 256,
+                                                      chunkable=torch.ones(n, dtype=torch.uint8, device=dev))   # (chunked prefill, as the run)
+            res["ref_sort_ok"] = bool(np.array_equal(perm_ref.cpu().numpy(), want))
+            res["ref_ran_ok"] = sorted(want[:int(n_sel_ref.item())].tolist()) == zf["a_ran"].tolist()
+            # an inversion (i before j in the reference's order, j before i in ours) whose reference gap exceeds G exists iff, for
+            # some j, a request more than G above it in the reference's scores sits behind it in our order: prefix maximum
+            pos = np.empty(n, np.int64); pos[perm_h] = np.arange(n)
+            p = pos[want]
+            sref = ref.astype(np.float64)[want]                            # non-increasing
+            G = 2.0 * res["ref_err"]
+            k = np.searchsorted(-sref, -(sref + G), side="left")          # requests [0, k[j]) are more than G above request j
+            cm = np.maximum.accumulate(p)
+            bad = (k > 0) & (cm[np.maximum(k - 1, 0)] > p)
+            res["ref_order_ok"] = not bool(bad.any())
+            res["ref_moved"] = int((perm_h != want).sum())
         dist.barrier()
         q.put(res)
     finally:
@@ -338,6 +364,9 @@ def test_config4_opt125m_64k_queue_sharded_over_8_ranks_full_size():
           f"sample of {r0['oracle_n']} requests, max|d| = {r0['oracle_err']:.3e}; shard tokens {r0['tok']}")
     assert r0["oracle_n"] >= 64 and r0["oracle_err"] <= 1e-4
     assert r0["perm_ok"] and r0["budget_ok"]
+    print(f"config 4 against the reference's own run of the 64k queue: max|d| = {r0['ref_err']:.3e} (rms {r0['ref_rms']:.3e}) over all "
+          f"65,536 scores; {r0['ref_moved']} positions of the end-to-end order differ, none by more than an fp32 near-tie")
+    assert r0["ref_err"] <= 1e-4 and r0["ref_sort_ok"] and r0["ref_ran_ok"] and r0["ref_order_ok"]
     assert max(r0["tok"]) - min(r0["tok"]) <= 2048                   # token-balanced within one maximal request
 
 

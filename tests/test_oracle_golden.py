@@ -213,6 +213,37 @@ def test_reserve_select_matches_reference_calls():
     assert all(v > 0 for v in seen.values()), seen
 
 
+def test_config4_queue_reference_run_literal_sort():
+    """BASELINE config 4's queue (65,536 requests, 5,734,532 tokens) scored and ordered by the reference (one cold Scheduler step,
+    oracle/make_config1_golden.py --config 4full): the literal promote / demote + stable sort of the reference's 65,536 scores is its
+    order, the numpy restatement agrees, the budget walk selects what its schedule() ran; the oracle predictor agrees with the
+    reference's on a handful of requests across the queue."""
+    import hashlib
+    from bench import synthetic_queue
+    z = np.load(os.path.join(GOLDEN, "config4_opt125m_65536.npz"), allow_pickle=False)
+    spec = OPTSpec.opt_125m()
+    n = 65536
+    ids, cu, lens = synthetic_queue(spec, n, seed=0)
+    assert int(cu[-1]) == 5734532
+    assert hashlib.sha256(np.ascontiguousarray(ids.astype(np.int32)).tobytes()).digest() == z["ids_sha256"].tobytes()
+    assert hashlib.sha256(np.ascontiguousarray(cu.astype(np.int32)).tobytes()).digest() == z["cu_sha256"].tobytes()
+    ref, want = z["ref_score"], z["a_order"][0]
+    assert sorted(want.tolist()) == list(range(n))
+    order = rs.opt_order([rs.Req(str(i), float(ref[i])) for i in range(n)], int(z["a_starv"]), int(z["a_period"]))
+    assert [int(r.request_id) for r in order] == want.tolist()
+    zero = np.zeros(n, np.int32)
+    assert np.array_equal(rs.rank_step_np(ref, zero.copy(), zero.copy(), zero.copy(), int(z["a_starv"]), int(z["a_period"])), want)
+    nsel, granted = rs.budget_walk(lens[want], np.ones(n, np.int32), int(z["a_token_budget"]), int(z["a_max_num_seqs"]), np.ones(n, np.uint8))
+    assert sorted(want[:nsel].tolist()) == z["a_ran"].tolist()
+    pick = sorted({0, n - 1, int(want[0]), int(want[-1])} | set(np.random.RandomState(3).randint(0, n, 12).tolist()))
+    ids_s = np.concatenate([ids[cu[i]:cu[i + 1]] for i in pick]).astype(np.int64)
+    cu_s = np.concatenate([[0], np.cumsum(lens[pick])]).astype(np.int32)
+    got = OracleOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"]))).score_packed(ids_s, cu_s)
+    err = float(np.abs(got - ref[pick]).max())
+    print(f"config 4 queue: oracle vs the reference's predictor on {len(pick)} of the 65,536 requests: max|d| = {err:.3e}")
+    assert err <= 1e-5
+
+
 # ---- BASELINE config 1, run end to end by the reference (oracle/make_config1_golden.py) ----------------------------
 def _config1():
     return np.load(os.path.join(GOLDEN, "config1_opt125m_256.npz"), allow_pickle=False)
