@@ -188,13 +188,15 @@ FULL_RUNS = {"config2": ("config2_opt125m_8192.npz", OPTSpec.opt_125m, 64.0, 708
              "config3": ("config3_opt350m_8192.npz", OPTSpec.opt_350m, 128.0, 1407401)}
 
 
+@pytest.mark.parametrize("mode", ["f16", "f32"])
 @pytest.mark.parametrize("which", list(FULL_RUNS))
-def test_full_queue_against_the_reference_run(which):
+def test_full_queue_against_the_reference_run(which, mode):
     """BASELINE configs 2 and 3 at FULL size against the REFERENCE itself (tests/golden/config2_opt125m_8192.npz /
     config3_opt350m_8192.npz, written by oracle/make_config1_golden.py --config 2 / 3full: one cold step of the reference's
     Scheduler with its fp32 predictor on all 8,192 requests): every HIP score within the north-star tolerance of the
     reference's, the HIP sort of the REFERENCE's scores bit-identical to the reference's order, and the end-to-end order
-    (HIP scores -> HIP sort) differing from it only in fp32 near-ties."""
+    (HIP scores -> HIP sort) differing from it only in fp32 near-ties.  ``mode``: the product's split-fp16 arithmetic, and the
+    exact-f32 mode (f32 weights, f32 MFMA / VALU kernels)."""
     import hashlib
     import os
     from vllm_ltr_amd.rank import RankWorkspace, budget_prefix, rank_step
@@ -209,10 +211,10 @@ def test_full_queue_against_the_reference_run(which):
     ref = z["ref_score"]
     want = z["a_order"][0]
     assert (want >= 0).all() and sorted(want.tolist()) == list(range(8192))
-    sc = HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", "f16")
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, int(z["seed"])), "cuda:0", mode)
     hip = sc.score(ids, cu)
     err = np.abs(hip.astype(np.float64) - ref.astype(np.float64))
-    print(f"{which}, all 8,192 requests ({int(cu[-1]):,} tokens) against the reference's fp32 predictor: max|d| = {err.max():.3e}, "
+    print(f"{which} [{mode}], all 8,192 requests ({int(cu[-1]):,} tokens) against the reference's fp32 predictor: max|d| = {err.max():.3e}, "
           f"rms {np.sqrt((err ** 2).mean()):.3e}")
     assert err.max() <= TOL
     ws = RankWorkspace(dev)
@@ -220,7 +222,7 @@ def test_full_queue_against_the_reference_run(which):
     assert perm_ref.tolist() == want.tolist()                       # the reference's scores through the HIP sort: its order, bit for bit
     perm = rank_step(torch.from_numpy(hip).to(dev), None, None, None, -1, 0, ws).cpu().numpy()
     n_inv, worst = _inversions_worst_gap(want, perm, ref)
-    print(f"{which} END-TO-END order of the 8,192-request queue against the reference's: {n_inv} discordant pairs of "
+    print(f"{which} [{mode}] END-TO-END order of the 8,192-request queue against the reference's: {n_inv} discordant pairs of "
           f"{8192 * 8191 // 2}, largest reference-score gap among them {worst:.3e} (score error {err.max():.3e}; closest pair of "
           f"reference scores {np.diff(np.sort(ref.astype(np.float64))).min():.3e})")
     assert worst <= 2 * float(err.max())
