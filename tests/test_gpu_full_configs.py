@@ -188,7 +188,7 @@ FULL_RUNS = {"config2": ("config2_opt125m_8192.npz", OPTSpec.opt_125m, 64.0, 708
              "config3": ("config3_opt350m_8192.npz", OPTSpec.opt_350m, 128.0, 1407401)}
 
 
-@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("mode", ["f16", "f32", "f16-1pass"])
 @pytest.mark.parametrize("which", list(FULL_RUNS))
 def test_full_queue_against_the_reference_run(which, mode):
     """BASELINE configs 2 and 3 at FULL size against the REFERENCE itself (tests/golden/config2_opt125m_8192.npz /
@@ -196,7 +196,8 @@ def test_full_queue_against_the_reference_run(which, mode):
     Scheduler with its fp32 predictor on all 8,192 requests): every HIP score within the north-star tolerance of the
     reference's, the HIP sort of the REFERENCE's scores bit-identical to the reference's order, and the end-to-end order
     (HIP scores -> HIP sort) differing from it only in fp32 near-ties.  ``mode``: the product's split-fp16 arithmetic, and the
-    exact-f32 mode (f32 weights, f32 MFMA / VALU kernels)."""
+    exact-f32 mode (f32 weights, f32 MFMA / VALU kernels); ``f16-1pass`` (LTR_F_ONE_PASS: the reference's own fp16 GPU arithmetic,
+    opt-in, OUTSIDE the 1e-4 contract) only reports its distance and how much of the order it moves."""
     import hashlib
     import os
     from vllm_ltr_amd.rank import RankWorkspace, budget_prefix, rank_step
@@ -216,7 +217,7 @@ def test_full_queue_against_the_reference_run(which, mode):
     err = np.abs(hip.astype(np.float64) - ref.astype(np.float64))
     print(f"{which} [{mode}], all 8,192 requests ({int(cu[-1]):,} tokens) against the reference's fp32 predictor: max|d| = {err.max():.3e}, "
           f"rms {np.sqrt((err ** 2).mean()):.3e}")
-    assert err.max() <= TOL
+    assert err.max() <= (2e-2 if mode == "f16-1pass" else TOL)
     ws = RankWorkspace(dev)
     perm_ref = rank_step(torch.from_numpy(ref).to(dev), None, None, None, -1, 0, ws).cpu().numpy()
     assert perm_ref.tolist() == want.tolist()                       # the reference's scores through the HIP sort: its order, bit for bit
