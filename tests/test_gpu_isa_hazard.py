@@ -39,3 +39,15 @@ def test_only_lint_rejected_forms_differ():
     r = _run("pk_opsel_probe", "2", "quick")
     assert r.returncode in (0, 1), (r.stdout + r.stderr)[-3000:]          # 2 = a form the library may contain differed
     print(r.stdout.strip().splitlines()[-1])
+
+
+def test_wide_store_needs_two_wait_states_before_its_data_is_overwritten():
+    """The second hazard the build lints for (isa_lint.py rule 2, profiles/r06_store_policy.txt), on the hardware: a VALU write into a
+    data register of a 16-byte store lands in memory when it follows the store by 0 wait states (about a quarter of the overwritten
+    words) or, rarely, by 1; never by 2 - the distance the library's asm epilogue stores now carry (`s_nop 1`).  The probe exits
+    non-zero if a word is wrong behind two wait states; the 0-wait-state line documents that the hazard is real on this box."""
+    r = _run("store_hazard_probe", timeout=300)
+    assert r.returncode == 0 and "wrong words with two wait states: 0" in r.stdout, (r.stdout + r.stderr)[-2000:]
+    first = r.stdout.strip().splitlines()[0]
+    print(first)
+    assert "after 0 wait state" in first and int(first.split(":")[1].split()[0]) > 0, first

@@ -326,3 +326,21 @@ def test_scoring_soak_with_a_busy_gpu():
                        text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "busy-GPU stress ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
     print(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("model", ["125m", "350m"])
+def test_store_policy_of_small_passes_is_invisible(model, monkeypatch):
+    """Small passes store their GEMM outputs with the default cache policy instead of non-temporal (ltr_api.hip ChunkRun::begin,
+    LTR_PLAIN_MB: the reader finds them in the Infinity Cache): the scores are the same bits with the rule off (0), on for every
+    pass size, and at its default."""
+    from vllm_ltr_amd.scorer import HipOPTScorer
+    spec = OPTSpec.opt_350m() if model == "350m" else OPTSpec.opt_125m()
+    sc = HipOPTScorer(spec, seeded_checkpoint(spec, 0), "cuda:0", "f16")
+    for k in (1, 5, 16, 96):
+        lens = bench_lengths(max(k, 256), seed=3)[:k]
+        ids, cu = synthetic_batch(spec, lens.tolist(), 7)
+        monkeypatch.delenv("LTR_PLAIN_MB", raising=False)
+        want = sc.score(ids, cu)
+        for mb in ("0", "1000000"):
+            monkeypatch.setenv("LTR_PLAIN_MB", mb)
+            assert np.array_equal(sc.score(ids, cu), want), (k, mb)

@@ -48,3 +48,43 @@ def test_round5_expression_is_what_the_lint_rejects(tmp_path):
     assert r.returncode == 0, r.stderr
     found = isa_lint.lint([str(obj)])
     assert found and all("splitk_epilogue_kernel" in k and "v_pk_mul_f32" in ins for _, k, ins in found), found
+
+
+def test_lint_sees_a_valu_write_into_the_data_of_a_wide_store(tmp_path):
+    """Second rule: a VALU write of a data register of a > 64-bit store within two wait states of it (the store reads its data over
+    several cycles; the compiler keeps the distance behind its own stores, not behind one inside an asm statement)."""
+    src = tmp_path / "planted_store.hip"
+    src.write_text(r'''
+#include <hip/hip_runtime.h>
+__global__ void planted_bad(float* o) {
+  asm volatile("global_store_dwordx4 %0, v[10:13], off nt\n\tv_mov_b32 v12, 0" ::"v"(o + threadIdx.x * 4) : "v10", "v11", "v12", "v13", "memory");
+}
+__global__ void planted_one_state(float* o) {
+  asm volatile("global_store_dwordx4 %0, v[10:13], off\n\ts_nop 0\n\tv_add_f32 v10, v10, v10" ::"v"(o + threadIdx.x * 4) : "v10", "v11", "v12", "v13", "memory");
+}
+__global__ void planted_fine(float* o) {
+  asm volatile("global_store_dwordx4 %0, v[10:13], off nt\n\ts_nop 1\n\tv_mov_b32 v12, 0" ::"v"(o + threadIdx.x * 4) : "v10", "v11", "v12", "v13", "memory");
+  asm volatile("global_store_dwordx2 %0, v[10:11], off\n\tv_mov_b32 v10, 0" ::"v"(o + threadIdx.x * 4) : "v10", "v11", "memory");   // 64 bits: no hazard
+  asm volatile("global_store_dwordx4 %0, v[10:13], off\n\tv_mov_b32 v14, 0" ::"v"(o + threadIdx.x * 4) : "v10", "v11", "v12", "v13", "v14", "memory");
+}
+''')
+    obj = tmp_path / "planted_store.o"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    found = isa_lint.lint([str(obj)])
+    assert len(found) == 2 and all(ins.startswith("store-data hazard") for _, _, ins in found), found
+    assert sorted("bad" in k or "one_state" in k for _, k, _ in found) == [True, True] and not any("fine" in k for _, k, _ in found)
+    with pytest.raises(RuntimeError, match="wait states"):
+        isa_lint.check([str(obj)])
+
+
+def test_stores_of_rounds_2_to_6_are_what_the_second_rule_rejects(tmp_path):
+    """ltr_gemm.hip with its asm stores as rounds 2-6 shipped them (no wait states behind the store: -DLTR_EPI_POST="") has VALU writes
+    into store data one instruction behind the store - what corrupted the a' planes the moment the code around the stores changed
+    (profiles/r06_store_policy.txt); the shipped file has none."""
+    obj = tmp_path / "gemm_nopost.o"
+    r = subprocess.run([HIPCC, *build.FLAGS, '-DLTR_EPI_POST=""', "-c", os.path.join(build.HERE, "ltr_gemm.hip"), "-o", str(obj)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    found = isa_lint.lint([str(obj)])
+    assert len(found) >= 8 and all(ins.startswith("store-data hazard") and " nt " in ins for _, _, ins in found), found[:3]

@@ -67,7 +67,9 @@ def build(force: bool = False) -> str:
 # element-level checker of the GEMM's LayerNorm-fold epilogues (diag/gemm_check.hip), run by the -m gpu tests
 TOOLS = {"gemm_check": os.path.join("diag", "gemm_check.hip"),
          # times the four dense layers of a decoder layer at M rows through launch_gemm (A/B of tile / split-K / XCD-map choices)
-         "gemm_bench": os.path.join("diag", "gemm_bench.hip")}
+         "gemm_bench": os.path.join("diag", "gemm_bench.hip"),
+         # hardware probe: a VALU write into the data registers of a 16-byte store 0 / 1 / 2 wait states behind it (isa_lint's second rule)
+         "store_hazard_probe": os.path.join("diag", "store_hazard_probe.hip")}
 # reproducers of the round-5 concurrency fault (profiles/r06_rln_fault.txt); they compile ltr_gemm.hip into themselves and use
 # rocBLAS as the co-running library GEMM: name -> (source, extra flags)
 ROCBLAS = os.path.exists("/opt/rocm/lib/librocblas.so") and os.path.exists("/opt/rocm/include/rocblas/rocblas.h")

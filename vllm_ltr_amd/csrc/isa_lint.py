@@ -45,18 +45,85 @@ def device_code_objects(path: str, workdir: str) -> list[str]:
     return sorted(os.path.join(workdir, f) for f in os.listdir(workdir) if f.startswith(base + ".") and "amdgcn" in f)
 
 
+# Second rule (round 6, profiles/r06_store_policy.txt): a vector store of MORE THAN 64 BITS reads its data registers over several
+# cycles; on gfx940-class hardware a VALU instruction must not write one of them within two wait states of the store (LLVM:
+# GCNHazardRecognizer::createsVALUHazard, VALUWaitStates = 2 with gfx940 instructions).  The compiler keeps that distance behind the
+# stores it emits itself - it cannot for a store inside an asm statement (epi_store16).  The rule flags every VALU write of a
+# store's data registers closer than that, wherever the store came from.
+_WIDE_STORE = re.compile(r"^\s*(?:global|flat|buffer|scratch)_store_dwordx[34]\s+(.*)$")
+_VREG = re.compile(r"^v(\d+)$|^v\[(\d+):(\d+)\]$")
+STORE_DATA_WAIT_STATES = 2
+
+
+def _vrange(tok: str):
+    m = _VREG.match(tok.strip())
+    if not m:
+        return None
+    return (int(m.group(1)),) * 2 if m.group(1) is not None else (int(m.group(2)), int(m.group(3)))
+
+
+def _store_data(args: str):
+    """Data registers of a wide store: the widest VGPR range among its operands (address pairs are two registers wide)."""
+    best = None
+    for tok in args.split(","):
+        r = _vrange(tok.split()[0] if tok.split() else "")
+        if r and r[1] - r[0] >= 2 and (best is None or r[1] - r[0] > best[1] - best[0]):
+            best = r
+    return best
+
+
+def _store_data_hazards(ins: list[str]) -> list[tuple[int, str]]:
+    """ins: the instructions of one kernel (text before the // comment).  Returns (index of the store, description)."""
+    out = []
+    for i, line in enumerate(ins):
+        m = _WIDE_STORE.match(line)
+        if not m:
+            continue
+        data = _store_data(m.group(1))
+        if data is None:
+            continue
+        ws, k = 0, i + 1
+        while ws < STORE_DATA_WAIT_STATES and k < len(ins):
+            parts = ins[k].split(None, 1)
+            op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+            if op == "s_nop":
+                ws += int(args.strip() or "0", 0) + 1
+                k += 1
+                continue
+            if op.startswith("v_"):
+                dst = _vrange(args.split(",")[0]) if args else None
+                if dst and not (dst[1] < data[0] or dst[0] > data[1]):
+                    out.append((i, f"{line.strip()}  <-  {ins[k].strip()}  ({ws} wait state(s) after the store)"))
+                    break
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64") or op.startswith("s_cbranch"):
+                break                     # (control flow: the fall-through / target start a new window; the compiler's stores are safe there)
+            ws += 1
+            k += 1
+    return out
+
+
 def lint_code_object(co: str) -> list[tuple[str, str]]:
     r = subprocess.run([OBJDUMP, "-d", co], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"llvm-objdump -d {co} failed:\n{r.stderr}")
-    found, kernel = [], "?"
+    found, kernel, body = [], "?", []
+
+    def flush():
+        for _, desc in _store_data_hazards(body):
+            found.append((kernel, "store-data hazard: " + desc))
+
     for line in r.stdout.splitlines():
         m = _LABEL.match(line)
         if m:
-            kernel = m.group(1)
+            flush()
+            kernel, body = m.group(1), []
             continue
+        text = line.split("//")[0].strip()
+        if text:
+            body.append(text)
         if _BAD.search(line):
-            found.append((kernel, line.split("//")[0].strip()))
+            found.append((kernel, text))
+    flush()
     return found
 
 
@@ -74,6 +141,13 @@ def lint(paths: list[str]) -> list[tuple[str, str, str]]:
 
 def check(paths: list[str]) -> None:
     bad = lint(paths)
+    hz = [b for b in bad if b[2].startswith("store-data hazard")]
+    if hz:
+        lines = "\n".join(f"  {f}: {k}: {ins}" for f, k, ins in hz[:20])
+        raise RuntimeError(
+            f"ISA lint: {len(hz)} VALU write(s) of the data registers of a > 64-bit store within {STORE_DATA_WAIT_STATES} wait states of it "
+            f"(the store may pick up the new value; profiles/r06_store_policy.txt).  A store inside an asm statement must carry its own "
+            f"wait states (`s_nop 1` behind it):\n{lines}")
     if bad:
         lines = "\n".join(f"  {f}: {k}: {ins}" for f, k, ins in bad[:20])
         raise RuntimeError(

@@ -240,6 +240,7 @@ struct ChunkRun {
   const int wd, H, F, De, Tc, nreq;
   int nl = 0;
   bool fold = false, ln1_folded = false;
+  bool plain_all = false;      // GemmArgs::store_plain of this pass's launches (small passes: begin())
   bool comb1_valid = false, comb2_valid = false;   // ws.comb1 / comb2 hold the combined statistics of the current stats1 / stats2
   // rows / buffers of the part of a layer after attention: all Tc token rows, except in the
   // last layer of a scoring call where only the nreq last-token rows are carried on (below)
@@ -260,6 +261,7 @@ struct ChunkRun {
                                                // the last layer's K | V, which the VALU last-query kernel reads as hi + lo
     }
     // the dominant kernel (128 x 256 tiles) and the small-batch kernels are timed as separate classes
+    if (plain_all) g.store_plain = 1;
     ProfScope p(m, wd == LTR_W_F16 && gemm_small_config(g) >= 0 ? LTR_K_GEMM_SMALL : LTR_K_GEMM, 2.0 * g.M * (double)g.N * g.K, s);
     return launch_gemm(wd, g, s);
   }
@@ -298,6 +300,18 @@ int ChunkRun::begin() {
   // ws.stats1 were written by the previous layer's fc2.
   fold = m->ln_fold;
   ln1_folded = false;
+  // Cache policy of the GEMM epilogues' stores.  Non-temporal stores keep a full-size pass's 1.4 GB of outputs per launch from
+  // sweeping the operand panels out of the L2s (-1.4 % on the 8k-queue call) - and send them to HBM, where the next launch reads
+  // them at the HBM rate.  The outputs of a SMALL pass fit the 256 MiB Infinity Cache: stored with the default policy their
+  // reader - the next launch - finds them there.  Measured on one box (profiles/r06_store_policy.txt): one or two arrivals
+  // -5 %, eight -2 %, sixteen -1.5 ... -3 %; from ~4k tokens per pass on it is a wash (the attention reads q | k | v 10 % faster,
+  // the GEMM that wrote them plainly loses as much to the lines its stores allocate in L2).  Rule: every output of the pass while
+  // its widest activation (rows x F, f32-sized) is <= LTR_PLAIN_MB (40: 3,413 tokens of OPT-125m, 2,560 of OPT-350m).
+  // Bit-identical either way.
+  {
+    const char* e = getenv("LTR_PLAIN_MB");           // (read per call: the lab moves it inside one process)
+    plain_all = wd == LTR_W_F16 && (double)Tc * F * 4.0 <= (e ? atof(e) : 40.0) * 1048576.0;
+  }
   return LTR_OK;
 }
 

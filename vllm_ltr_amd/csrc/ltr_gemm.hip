@@ -94,6 +94,7 @@ struct Epilogue {
   // null: the tile combines the pieces itself
   const float2* stats_comb;
   const float2* r_stats_comb;
+  int st_plain;           // GemmArgs::store_plain: default-policy stores instead of non-temporal ones (small passes)
 };
 
 // LNS rides on the consumer arithmetic v = (acc - mean c_n) rstd with mean = 0, c_n = 0, rstd = the output scale
@@ -186,17 +187,26 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #else
 #define LTR_EPI_PRE ""
 #endif
+#ifndef LTR_EPI_POST          // (-DLTR_EPI_POST="" rebuilds the stores of rounds 2-6 for the lint's own test)
+#define LTR_EPI_POST "\n\ts_nop 1"
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void epi_store16(void* p, const void* v) {
+__device__ __forceinline__ void epi_store16(void* p, const void* v, int plain) {
   const u32x4 d = *reinterpret_cast<const u32x4*>(v);
+  if (plain) { *reinterpret_cast<u32x4*>(p) = d; return; }      // (wave-uniform: a kernel argument)
 #if LTR_EPI_STORE == 1
   // Inline asm: the compiler's own __builtin_nontemporal_store costs out_proj 12 % (610 vs 545 us per 196k-token launch,
   // diag/gemm_bench.hip).  The operands are ordinary "v" inputs, so the compiler's waitcnt / hazard passes see what feeds them.
-  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+  // LTR_EPI_POST: a store of more than 64 bits reads its data registers over several cycles, and gfx940-class hardware needs two
+  // wait states before a VALU instruction may overwrite them (LLVM's hazard recognizer inserts them behind the stores IT emits;
+  // it does not look inside an asm statement).  Without them the next VALU write can land in the data of the store before it:
+  // round 2's "stale registers in one lane of 16", and - round 6 - wrong a' planes as soon as the code around the store changed
+  // (profiles/r06_store_policy.txt).  The wait states belong to the asm statement; isa_lint.py checks the built code for the hazard.
+  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off nt" LTR_EPI_POST ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 2
-  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off sc1" LTR_EPI_POST ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 3
-  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+  asm volatile(LTR_EPI_PRE "global_store_dwordx4 %0, %1, off sc0 sc1" LTR_EPI_POST ::"v"(p), "v"(d) : "memory");
 #elif LTR_EPI_STORE == 5
   __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(p));
 #else
@@ -317,8 +327,8 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
   x[0] += ra.x; x[1] += ra.y; x[2] += ra.z; x[3] += ra.w;
   x[4] += rb.x; x[5] += rb.y; x[6] += rb.z; x[7] += rb.w;
   if (ep.out_f32) {
-    epi_store16(ep.out_f32 + o, x);
-    epi_store16(ep.out_f32 + o + (ccol_b - ccol), x + 4);
+    epi_store16(ep.out_f32 + o, x, ep.st_plain);
+    epi_store16(ep.out_f32 + o + (ccol_b - ccol), x + 4, ep.st_plain);
   }
   if (ep.out_hi) {
     __half h[8], l[8];
@@ -329,8 +339,8 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
     if (h[0] == __half(12345.f) && l[7] == __half(54321.f))
 #endif
     {
-      epi_store16((__half*)ep.out_hi + os, h);
-      if (!ep.no_lo_out) epi_store16((__half*)ep.out_lo + os, l);
+      epi_store16((__half*)ep.out_hi + os, h, ep.st_plain);
+      if (!ep.no_lo_out) epi_store16((__half*)ep.out_lo + os, l, ep.st_plain);
     }
   }
   if (LNM == LNP) {
@@ -359,8 +369,8 @@ __device__ __forceinline__ void epilogue_piece(const Epilogue& ep, float4 va, fl
     const uint4 lv = odd ? make_uint4(lr.x, lr.y, lk.x, lk.y) : make_uint4(lk.x, lk.y, lr.x, lr.y);
     const int c0 = odd ? ccol_b - 4 : ccol;               // first of my 8 consecutive columns
     const size_t oo = slab_off(grow, c0, ldm);
-    epi_store16((__half*)ep.ln_hi + oo, &hv);
-    if (!ep.no_lo_out) epi_store16((__half*)ep.ln_lo + oo, &lv);
+    epi_store16((__half*)ep.ln_hi + oo, &hv, ep.st_plain);
+    if (!ep.no_lo_out) epi_store16((__half*)ep.ln_lo + oo, &lv, ep.st_plain);
     // (mean, M2) of this 64-column piece of the row (the shuffle partners lane ^ 1, 2, 4 hold the same
     // row, so they are active exactly when this lane is)
     float sm = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
@@ -1205,7 +1215,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
   Epilogue ep{g.bias, g.resid, g.out_f32, g.out_split.hi, g.out_split.lo, Mend, g.N, g.relu, g.a_slab, g.out_slab,
               g.ln_gamma, g.ln_out.hi, g.ln_out.lo, (float2*)g.ln_stats_out, (const float2*)g.ln_stats_in, g.ln_c,
               g.ln_parts, g.err_flag, (const float2*)g.rln_stats, g.rln_gamma, g.rln_beta, g.rln_parts, g.osc_a, g.osc_b,
-              g.row0, ldm, g.one_pass, g.no_lo_out, (const float2*)g.ln_stats_comb, (const float2*)g.rln_stats_comb};
+              g.row0, ldm, g.one_pass, g.no_lo_out, (const float2*)g.ln_stats_comb, (const float2*)g.rln_stats_comb, g.store_plain};
   const int lnm = g.ln_gamma ? LNP : (g.ln_stats_in ? LNC : (g.osc_a ? LNS : LN_NONE));
   if (g.osc_a && (wdtype != LTR_W_F16 || !g.osc_b || g.ln_gamma || g.ln_stats_in || g.rln_stats)) {
     set_error("gemm: scaled operands (osc_a / osc_b) need F16 mode, both scales and no LayerNorm fold");
@@ -1280,6 +1290,7 @@ int launch_gemm(int wdtype, const GemmArgs& g, hipStream_t s) {
       // raw partials [parts][window rows][N]; the kernels index rows globally: bias the base by the window's first row
       epk.out_f32 = (float*)g.splitk_ws - (size_t)g.row0 * g.N; epk.M = Mend; epk.N = g.N; epk.a_slab = g.a_slab;
       epk.row0 = g.row0; epk.ldm = ldm; epk.one_pass = g.one_pass;
+      epk.st_plain = 1;            // the partials (<= 59 MB) are read back by the reduce launch right behind this one
       lnm_k = LN_NONE; rln_k = false;
     }
     const int kpart = g.K / parts;

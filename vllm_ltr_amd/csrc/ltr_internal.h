@@ -106,6 +106,11 @@ struct GemmArgs {
   int one_pass = 0;
   int no_lo_out = 0;
   int keep_lo_out = 0;   // (caller's note to ChunkRun::gemm: this output's lo plane has a reader that is not a one-pass kernel)
+  // F16 mode: store the outputs with the default cache policy instead of non-temporal.  The epilogue's nt stores stream a
+  // pass's 1.4 GB of outputs past the caches (they are re-read long after they have left them: -1.4 % on the full-size call);
+  // the outputs of a SMALL pass fit the 256 MiB Infinity Cache, where their reader - the next launch - finds them at twice
+  // the HBM rate (ltr_api.hip ChunkRun::begin decides per pass; profiles/r06_store_policy.txt)
+  int store_plain = 0;
 };
 
 // launchers (each in its own .hip file)
