@@ -1,5 +1,5 @@
 """Randomised parity soak (not collected by pytest): HIP kernels vs the oracle on many random shapes.
-    python tests/diag/fuzz_gpu.py [seconds]"""
+    python tests/diag/fuzz_gpu.py [seconds]        (LTR_FUZZ_SEED=<n> replays a run; the seed is printed)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,9 @@ from vllm_ltr_amd.scorer import HipOPTScorer
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 dev = "cuda:0"
-r = np.random.RandomState(int(time.time()) % 100000)
+seed = int(os.environ.get("LTR_FUZZ_SEED", int(time.time()) % 100000))
+print(f"fuzz: LTR_FUZZ_SEED={seed}", flush=True)          # a red run replays with it
+r = np.random.RandomState(seed)
 t = lambda a: torch.from_numpy(a).to(dev)
 t0 = time.time(); n_rank = n_res = n_bud = n_score = 0
 ws = RankWorkspace(torch.device(dev))

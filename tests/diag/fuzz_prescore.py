@@ -1,6 +1,6 @@
 """Randomised soak of scoring at arrival (not collected by pytest): random arrival patterns (lone, clustered, bursts, requests
 that skip the hook), random step boundaries; every score against the oracle, every request scored once.
-    python tests/diag/fuzz_prescore.py [seconds]"""
+    python tests/diag/fuzz_prescore.py [seconds]        (LTR_FUZZ_SEED=<n> replays a run; the seed is printed)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,9 @@ from vllm_ltr_amd.plugin import MI355XRanker
 from vllm_ltr_amd.scorer import HipOPTScorer
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-r = np.random.RandomState(int(time.time()) % 100000)
+seed = int(os.environ.get("LTR_FUZZ_SEED", int(time.time()) % 100000))
+print(f"prescore fuzz: LTR_FUZZ_SEED={seed}", flush=True)          # a red run replays with it
+r = np.random.RandomState(seed)
 t0 = time.time()
 n_req = n_steps = n_aborted = 0
 worst = 0.0
