@@ -341,6 +341,7 @@ def main():
                     help="steady calls to time outside the timed region: k new requests scored + the whole queue re-ranked "
                          "(SURVEY 8d 'steady'); comma list, '0' = none")
     ap.add_argument("--no-strong", action="store_true", help="skip the 65,536-request strong-scaling point")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the host_inclusive block (profiling passes: keeps the launch counts of the run to the timed steps)")
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE config 3 block (OPT-350m, 8k lmsys queue) of the default run")
     ap.add_argument("--no-class-head", action="store_true",
                     help="skip the class-mode head measurement (8,192 requests x 8,192 labels, kernels.class_head)")
@@ -555,7 +556,7 @@ def main():
     # scores / order back: pinned H2D of ids + cu_seqlens, the call, pinned D2H of the scores and the order).  Reported beside
     # `value`, never as it (N = 1, outside the timed region).
     host_incl = None
-    if world == 1 and not args.sweep:
+    if world == 1 and not args.sweep and not args.no_host_inclusive:
         ids_h, cu_h = torch.from_numpy(ids).pin_memory(), torch.from_numpy(cu).pin_memory()
         sc_h = torch.empty(n_total, dtype=torch.float32).pin_memory()
         pm_h = torch.empty(n_total, dtype=torch.int32).pin_memory()

@@ -22,7 +22,7 @@ cd /tmp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/vllm_ltr_amd/csrc/diag/pmc_calib.hip -o /tmp/pmc_calib || exit 1
 rocprofv3 --pmc FETCH_SIZE -d $O/calib_fetch -o f -- /tmp/pmc_calib > $O/calib_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/calib_write -o w -- /tmp/pmc_calib > $O/calib_w.log 2>&1
-BENCH="python $R/bench.py $WL --steps 1 --warmup 0 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-scale-points --no-class-head --no-config3 --steady-new 0"
+BENCH="python $R/bench.py $WL --steps 1 --warmup 0 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-scale-points --no-class-head --no-config3 --no-host-inclusive --steady-new 0"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- $BENCH > $O/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- $BENCH > $O/pmc_w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_sq -o s -- $BENCH > $O/pmc_s.log 2>&1
@@ -36,7 +36,7 @@ python profiles/make_gemm_pmc.py $(db pmc_sq) $(db pmc_l2) $O/gemm_pmc$SUF.json 
 cp $O/gemm_pmc$SUF.json profiles/gemm_pmc$SUF.json
 python bench.py $WL > $O/bench.json 2> $O/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py $WL --steps 2 --warmup 1 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-scale-points --no-class-head --no-config3 --steady-new 0 > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python $R/bench.py $WL --steps 2 --warmup 1 --no-cpu-baseline --no-unfused --no-profile-pass --no-strong --no-scale-points --no-class-head --no-config3 --no-host-inclusive --steady-new 0 > $O/prof.log 2>&1
 cd $R
 python profiles/summarize_rocpd.py $(db prof) $O/kernel_stats.csv > $O/kernel_stats.txt 2>&1
 find $O -name "*.db" -delete
