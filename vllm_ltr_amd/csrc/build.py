@@ -17,8 +17,13 @@ SOURCES = ["ltr_api.hip", "ltr_rank.hip", "ltr_rows.hip", "ltr_gemm.hip", "ltr_a
 HEADERS = ["ltr_internal.h", os.path.join("..", "..", "include", "ltr_hip.h")]
 LIB = os.path.join(HERE, "libltr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-kernarg-preload-count: gfx950's command processor delivers the leading kernel arguments (pointers, sizes) in SGPRs at
+# wave launch, so a kernel's first address computation does not wait for an s_load of its kernarg segment - worth 0.14 us per
+# launch on the 79-launch one-request call (-1.7 % at k = 1, nothing on the cold call; bit-identical scores:
+# profiles/r06_kernarg_preload.txt).  LTR_NO_KERNARG_PRELOAD=1 builds without it (the A/B).
+PRELOAD = [] if os.environ.get("LTR_NO_KERNARG_PRELOAD") == "1" else ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"] + os.environ.get("LTR_HIPCC_EXTRA", "").split()
+         "-fno-gpu-rdc"] + PRELOAD + os.environ.get("LTR_HIPCC_EXTRA", "").split()
 
 
 # per-file flags: the attention kernel is bound by per-wave latency (a few hundred dependent VALU / LDS / MFMA
